@@ -1,0 +1,262 @@
+"""ctypes front-end of oracle/armnet_oracle.c (TEST INFRASTRUCTURE ONLY).
+
+The C file restates the reference's ATen op chain stage by stage (citations
+there).  This module only marshals numpy arrays and strings the stages
+together the way ARMNetModel.forward does (models/armnet_1h.py:76-98,
+models/armnet.py:77-101), driven by a reference-format ``state_dict``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libarmnet_oracle.so")
+_SRC = os.path.join(_HERE, "armnet_oracle.c")
+_lib = None
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i64 = ctypes.POINTER(ctypes.c_int64)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libarmnet_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_arm_block.restype = ctypes.c_int
+        _lib.oracle_embed.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(c_f)
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_f)
+
+
+def set_threads(n):
+    lib().armnet_oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().armnet_oracle_max_threads())
+
+
+def clamp_vals(vals):
+    assert vals.dtype == np.float32 and vals.flags["C_CONTIGUOUS"]
+    lib().oracle_clamp_vals(_fp(vals), ctypes.c_int64(vals.size))
+    return vals
+
+
+def embed(ids, vals, table):
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    B, F = ids.shape
+    nfeat, E = table.shape
+    vals, pv = _f(vals)
+    table, pt = _f(table)
+    x = np.empty((B, F, E), np.float32)
+    rc = lib().oracle_embed(ids.ctypes.data_as(c_i64), pv, pt, ctypes.c_int64(nfeat),
+                            ctypes.c_int64(B), F, E, _fp(x))
+    if rc != 0:
+        raise IndexError("index out of range in self")
+    return x
+
+
+def gates_1h(x, W, q):
+    B, F, E = x.shape
+    D = W.shape[0]
+    H = q.shape[0]
+    x, px = _f(x); W, pW = _f(W); q, pq = _f(q)
+    g = np.empty((B, H, F), np.float32)
+    lib().oracle_gates_1h(px, pW, pq, ctypes.c_int64(B), F, E, D, H, _fp(g))
+    return g
+
+
+def gates_mh(x, bw, q):
+    B, F, E = x.shape
+    K, _, D = bw.shape
+    H = q.shape[1]
+    x, px = _f(x); bw, pb = _f(bw); q, pq = _f(q)
+    g = np.empty((B, K, H, F), np.float32)
+    lib().oracle_gates_mh(px, pb, pq, ctypes.c_int64(B), F, E, D, K, H, _fp(g))
+    return g
+
+
+def entmax_bisect(X, alpha=1.5, n_iter=50, ensure_sum_one=True):
+    """utils/entmax.py:134 entmax_bisect(X, alpha, dim=-1, n_iter, ensure_sum_one)."""
+    X, pX = _f(X)
+    d = X.shape[-1]
+    rows = X.size // d
+    P = np.empty_like(X)
+    lib().oracle_entmax_bisect(pX, ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
+                               int(bool(ensure_sum_one)), _fp(P))
+    return P
+
+
+def softmax(X):
+    X, pX = _f(X)
+    d = X.shape[-1]
+    P = np.empty_like(X)
+    lib().oracle_softmax(pX, ctypes.c_int64(X.size // d), d, _fp(P))
+    return P
+
+
+def sparse_map(X, alpha, n_iter=50):
+    return softmax(X) if float(alpha) == 1.0 else entmax_bisect(X, alpha, n_iter)
+
+
+def interact_exp(x, p, values):
+    """p: [B,O,F], values: [O,F] -> (arm_weight [B,O,F], neurons [B,O,E])."""
+    B, F, E = x.shape
+    O = values.shape[0]
+    x, px = _f(x); p, pp = _f(p); values, pv = _f(values)
+    w = np.empty((B, O, F), np.float32)
+    z = np.empty((B, O, E), np.float32)
+    lib().oracle_interact_exp(px, pp, pv, ctypes.c_int64(B), F, E, O, _fp(w), _fp(z))
+    return w, z
+
+
+def bn_eval(x, w, b, mean, var, eps=1e-5):
+    x, px = _f(x)
+    B, C = x.shape[0], x.shape[1]
+    L = x.size // (B * C) if x.size else 1
+    w, pw = _f(w); b, pb = _f(b); mean, pm = _f(mean); var, pvv = _f(var)
+    y = np.empty_like(x)
+    lib().oracle_bn_eval(px, pw, pb, pm, pvv, ctypes.c_float(eps), ctypes.c_int64(B), C, L, _fp(y))
+    return y
+
+
+def bn_train(x, w, b, run_mean, run_var, eps=1e-5, momentum=0.1):
+    """Returns (y, new_running_mean, new_running_var)."""
+    x, px = _f(x)
+    B, C = x.shape[0], x.shape[1]
+    L = x.size // (B * C)
+    w, pw = _f(w); b, pb = _f(b)
+    rm = np.array(run_mean, dtype=np.float32, copy=True)
+    rv = np.array(run_var, dtype=np.float32, copy=True)
+    y = np.empty_like(x)
+    lib().oracle_bn_train(px, pw, pb, _fp(rm), _fp(rv), ctypes.c_float(eps), ctypes.c_float(momentum),
+                          ctypes.c_int64(B), C, L, _fp(y))
+    return y, rm, rv
+
+
+def linear(x, W, b=None):
+    x, px = _f(x); W, pW = _f(W)
+    B, I = x.shape
+    O = W.shape[0]
+    y = np.empty((B, O), np.float32)
+    if b is not None:
+        b, pb = _f(b)
+    else:
+        pb = None
+    lib().oracle_linear(px, pW, pb, ctypes.c_int64(B), I, O, _fp(y))
+    return y
+
+
+def mlp(x, sd, prefix, train=False):
+    """models/layers.py:68-88 — nn.Sequential of (Linear, BN1d, ReLU, Dropout)*n + Linear.
+    Layer indices in the state_dict: Linear at 4i, BatchNorm1d at 4i+1; last Linear at 4n."""
+    idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix)})
+    lin = [i for i in idx if (prefix + f"{i}.running_mean") not in sd]
+    h = x
+    for i in lin[:-1]:
+        h = linear(h, sd[prefix + f"{i}.weight"], sd[prefix + f"{i}.bias"])
+        j = i + 1
+        if train:
+            h, _, _ = bn_train(h, sd[prefix + f"{j}.weight"], sd[prefix + f"{j}.bias"],
+                               sd[prefix + f"{j}.running_mean"], sd[prefix + f"{j}.running_var"])
+        else:
+            h = bn_eval(h, sd[prefix + f"{j}.weight"], sd[prefix + f"{j}.bias"],
+                        sd[prefix + f"{j}.running_mean"], sd[prefix + f"{j}.running_var"])
+        h = np.maximum(h, 0.0)          # ReLU; Dropout is identity in eval (and p=0 in the fixtures)
+    i = lin[-1]
+    return linear(h, sd[prefix + f"{i}.weight"], sd[prefix + f"{i}.bias"])
+
+
+def forward(variant, ctor, sd, ids, vals, train=False, n_iter=50):
+    """Whole ARMNetModel.forward from a reference-format state_dict.
+
+    variant '1h' -> models/armnet_1h.py:76-98, 'mh' -> models/armnet.py:77-101.
+    Returns every intermediate the golden fixtures hold.  ``vals`` is copied; the clamped copy is
+    returned as ``vals_clamped`` (the reference clamps the caller's tensor in place)."""
+    out = {}
+    vals = np.array(vals, dtype=np.float32, copy=True)
+    clamp_vals(vals)
+    out["vals_clamped"] = vals
+    x = embed(ids, vals, sd["embedding.embedding.weight"])
+    out["x_emb"] = x
+    alpha = float(ctor["alpha"])
+    if variant == "1h":
+        g = gates_1h(x, sd["attn_layer.bilinear_w.weight"], sd["attn_layer.query"])
+        values = sd["attn_layer.values"]
+    else:
+        g = gates_mh(x, sd["attn_layer.bilinear_w"], sd["attn_layer.query"])
+        values = sd["attn_layer.values"]
+    out["gates"] = g
+    p = sparse_map(g, alpha, n_iter)
+    out["p"] = p
+    B = x.shape[0]
+    F = x.shape[1]
+    O = int(np.prod(values.shape[:-1]))
+    w, z = interact_exp(x, p.reshape(B, O, F), values.reshape(O, F))
+    out["arm_weight"] = w.reshape(g.shape)
+    out["neurons"] = z if variant == "1h" else z.reshape(B, O, -1)
+    if train:
+        xa, rm, rv = bn_train(z, sd["arm_bn.weight"], sd["arm_bn.bias"], sd["arm_bn.running_mean"],
+                              sd["arm_bn.running_var"])
+        out["after/arm_bn.running_mean"], out["after/arm_bn.running_var"] = rm, rv
+    else:
+        xa = bn_eval(z, sd["arm_bn.weight"], sd["arm_bn.bias"], sd["arm_bn.running_mean"],
+                     sd["arm_bn.running_var"])
+    out["x_arm"] = xa
+    y = mlp(xa.reshape(B, -1), sd, "mlp.mlp.", train=train)
+    if "ensemble_layer.weight" in sd:
+        xd = embed(ids, vals, sd["deep_embedding.embedding.weight"]).reshape(B, -1)
+        yd = mlp(xd, sd, "deep_mlp.mlp.", train=train)
+        y = linear(np.concatenate([y, yd], axis=1), sd["ensemble_layer.weight"], sd["ensemble_layer.bias"])
+    out["logits"] = np.squeeze(y)
+    return out
+
+
+def arm_block(variant, ids, vals, sd, alpha, n_iter=50, threads=None):
+    """Fused block a2..a9 (eval) in one OpenMP call; vals clamped IN PLACE.  Returns [B, O, E]."""
+    if threads:
+        set_threads(threads)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    assert vals.dtype == np.float32 and vals.flags["C_CONTIGUOUS"]
+    B, F = ids.shape
+    table, pt = _f(sd["embedding.embedding.weight"])
+    nfeat, E = table.shape
+    if variant == "1h":
+        bw, pb = _f(sd["attn_layer.bilinear_w.weight"]); D = bw.shape[0]; K = 1
+        q, pq = _f(sd["attn_layer.query"]); H = q.shape[0]
+    else:
+        bw, pb = _f(sd["attn_layer.bilinear_w"]); K, _, D = bw.shape
+        q, pq = _f(sd["attn_layer.query"]); H = q.shape[1]
+    v, pv = _f(sd["attn_layer.values"])
+    w, pw = _f(sd["arm_bn.weight"]); b, pbb = _f(sd["arm_bn.bias"])
+    m, pm = _f(sd["arm_bn.running_mean"]); var, pvar = _f(sd["arm_bn.running_var"])
+    out = np.empty((B, K * H, E), np.float32)
+    rc = lib().oracle_arm_block(0 if variant == "1h" else 1, ctypes.c_int64(B), F, E, D, K, H,
+                                ctypes.c_float(alpha), int(n_iter), ids.ctypes.data_as(c_i64), _fp(vals),
+                                pt, ctypes.c_int64(nfeat), pb, pq, pv, pw, pbb, pm, pvar,
+                                ctypes.c_float(1e-5), _fp(out))
+    if rc == -3:
+        raise IndexError("index out of range in self")
+    if rc != 0:
+        raise RuntimeError(f"oracle_arm_block failed: {rc}")
+    return out

@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs ONLY in the build container, where the upstream reference is mounted at
+/root/reference (override with ARMNET_REFERENCE).  It imports the reference's
+own modules (models/armnet.py, models/armnet_1h.py, utils/entmax.py), drives
+them on CPU with fixed seeds and captures, through forward hooks, every
+intermediate tensor of the hot path:
+
+    x_emb      embedding(ids) * clamp(vals)            layers.py:20-21
+    gates      scaled bilinear attention logits        armnet_1h.py:30-32 / armnet.py:33-34
+    p          entmax / softmax over the fields        entmax.py:29-68
+    arm_weight p * values                              armnet_1h.py:34 / armnet.py:36
+    neurons    exp(einsum(x_emb, arm_weight))          armnet_1h.py:85-86 / armnet.py:86-87
+    x_arm      arm_bn(neurons)                         armnet_1h.py:85 / armnet.py:89
+    logits     full forward                            armnet_1h.py:98 / armnet.py:101
+    vals_clamped  the in-place side effect on x['value']  armnet_1h.py:81
+
+Nothing of the reference's source travels: the .npz files hold only inputs,
+parameters (state_dict) and outputs.  Usage:
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+REF = os.environ.get("ARMNET_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+sys.path.insert(0, REF)
+from models.armnet import ARMNetModel as RefMH  # noqa: E402
+from models.armnet_1h import ARMNetModel as Ref1H  # noqa: E402
+from utils.entmax import entmax_bisect as ref_entmax_bisect  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def _stress(model, gen):
+    """'stress' weight regime of SURVEY.md §8c: sparse supports, wide exp range, live BN affine."""
+    with torch.no_grad():
+        w = model.embedding.embedding.weight
+        w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
+        model.attn_layer.query.mul_(4.0)
+        for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]:
+            if bn is model.arm_bn:      # the fused block's BN: strongly non-trivial affine
+                bn.running_mean.copy_(torch.rand(bn.running_mean.shape, generator=gen) + 0.5)
+                bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=gen) * 1.5 + 0.5)
+            else:                       # head BNs: mild, so the ReLUs stay alive and logits vary
+                bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=gen) * 0.05)
+                bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=gen) * 0.4 + 0.8)
+            bn.weight.copy_(torch.rand(bn.weight.shape, generator=gen) + 0.5)
+            bn.bias.copy_(torch.randn(bn.bias.shape, generator=gen) * 0.1)
+        if hasattr(model, "deep_embedding"):
+            w = model.deep_embedding.embedding.weight
+            w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
+
+
+def _inputs(B, F, nfeat, gen):
+    ids = torch.randint(0, nfeat, (B, F), generator=gen, dtype=torch.int64)
+    vals = torch.rand(B, F, generator=gen)
+    # rows the reference's clamp must act on: 0, >1, negative; plus duplicate ids in one sample
+    vals[0, 0] = 0.0
+    vals[0, 1] = 2.5
+    vals[1, 0] = -0.7
+    vals[1, 2] = 1.0
+    vals[2, :] = 1.0
+    if F >= 4:
+        ids[3, 1] = ids[3, 0]
+        ids[3, 3] = ids[3, 0]
+    ids[4, 0] = 0
+    ids[4, F - 1] = nfeat - 1
+    return ids, vals
+
+
+def _capture(model, ids, vals, train=False):
+    cap = {}
+    hooks = []
+
+    def once(name, fn):
+        def hook(mod, inp, out):
+            if name not in cap:
+                fn(inp, out)
+        return hook
+
+    hooks.append(model.embedding.register_forward_hook(
+        once("x_emb", lambda i, o: cap.__setitem__("x_emb", o.detach().clone()))))
+
+    def sp(i, o):
+        cap["gates"] = i[0].detach().clone()
+        cap["p"] = o.detach().clone()
+    hooks.append(model.attn_layer.sparsemax.register_forward_hook(once("p", sp)))
+    hooks.append(model.attn_layer.register_forward_hook(
+        once("arm_weight", lambda i, o: cap.__setitem__("arm_weight", o.detach().clone()))))
+
+    def bn(i, o):
+        cap["neurons"] = i[0].detach().clone()
+        cap["x_arm"] = o.detach().clone()
+    hooks.append(model.arm_bn.register_forward_hook(once("x_arm", bn)))
+
+    x = {"id": ids.clone(), "value": vals.clone(), "y": torch.zeros(ids.shape[0])}
+    if train:
+        model.train()
+        y = model(x)
+    else:
+        model.eval()
+        with torch.no_grad():
+            y = model(x)
+    for h in hooks:
+        h.remove()
+    cap["logits"] = y.detach().clone()
+    cap["vals_clamped"] = x["value"].detach().clone()
+    return cap
+
+
+def _save(name, meta, sd, ids, vals, cap):
+    out = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
+    out["in/ids"] = ids.numpy()
+    out["in/vals"] = vals.numpy()
+    for k, v in sd.items():
+        out["sd/" + k] = v.detach().cpu().numpy()
+    for k, v in cap.items():
+        out["out/" + k] = v.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:42s} {os.path.getsize(path) / 1024:8.1f} KiB  logits[:3]={cap['logits'].flatten()[:3].tolist()}")
+
+
+def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=False):
+    """ctor: dict of constructor args in the reference's own names."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    if variant == "1h":
+        m = Ref1H(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["alpha"], ctor["nhid"], ctor["d_k"],
+                  ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"],
+                  ctor["deep_nlayer"], ctor["deep_nhid"])
+    else:
+        m = RefMH(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhead"], ctor["alpha"], ctor["nhid"],
+                  ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"],
+                  ctor["deep_nlayer"], ctor["deep_nhid"])
+    if regime == "stress":
+        _stress(m, gen)
+    if ids is None:
+        ids, vals = _inputs(B, ctor["nfield"], ctor["nfeat"], gen)
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    cap = _capture(m, ids, vals, train=train)
+    meta = dict(name=name, variant=variant, ctor=ctor, regime=regime, seed=seed, train=train,
+                torch=torch.__version__)
+    if train:
+        # train mode updates BN running statistics: keep both sides of the step
+        for k, v in m.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                cap["after/" + k] = v.clone()
+    _save(name, meta, sd_before, ids, vals, cap)
+
+
+def frappe_rows(n):
+    ids, vals = [], []
+    with open(os.path.join(REF, "data/frappe/test.libsvm")) as f:
+        for line in f:
+            cols = line.split(" ")[1:]
+            ids.append([int(c.split(":")[0]) for c in cols])
+            vals.append([float(c.split(":")[1]) for c in cols])
+            if len(ids) == n:
+                break
+    return torch.tensor(ids, dtype=torch.int64), torch.tensor(vals, dtype=torch.float32)
+
+
+def base(nfield, nfeat, nemb, alpha, nhid, **kw):
+    d = dict(nfield=nfield, nfeat=nfeat, nemb=nemb, alpha=alpha, nhid=nhid, d_k=nemb, nhead=1,
+             mlp_nlayer=2, mlp_nhid=32, dropout=0.0, ensemble=False, deep_nlayer=2, deep_nhid=32)
+    d.update(kw)
+    return d
+
+
+def entmax_cases():
+    """G6: the sparse map alone (utils/entmax.py:134-175) + its edge rows."""
+    gen = torch.Generator().manual_seed(77)
+    out = {}
+    meta = []
+    for d in (39, 10, 22, 43, 1, 64, 100):
+        for alpha in (1.5, 1.7, 2.0, 1.2, 2.5):
+            for scale in (0.01, 0.3, 1.5, 6.0):
+                rows = 24 if d <= 43 else 8
+                X = torch.randn(rows, d, generator=gen) * scale
+                if d >= 4:
+                    X[0] = 0.0                      # all equal -> uniform
+                    X[1] = 0.0
+                    X[1, 2] = 50.0                  # one dominant -> one-hot
+                    X[2, : d // 2] = X[2, 0]        # ties
+                    X[3] = torch.linspace(-1, 1, d) * scale
+                key = f"d{d}_a{alpha}_s{scale}"
+                out["X/" + key] = X.numpy()
+                out["P/" + key] = ref_entmax_bisect(X, alpha=alpha, dim=-1, n_iter=50).numpy()
+                meta.append(dict(key=key, d=d, alpha=alpha, scale=scale, n_iter=50))
+    # non-default iteration counts (entmax.py:134 n_iter) and the un-normalised variant
+    X = torch.randn(32, 39, generator=gen) * 1.5
+    for n_iter in (1, 5, 12, 24):
+        key = f"niter{n_iter}"
+        out["X/" + key] = X.numpy()
+        out["P/" + key] = ref_entmax_bisect(X, alpha=1.7, dim=-1, n_iter=n_iter).numpy()
+        meta.append(dict(key=key, d=39, alpha=1.7, scale=1.5, n_iter=n_iter))
+    key = "nosum1"
+    out["X/" + key] = X.numpy()
+    out["P/" + key] = ref_entmax_bisect(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=False).numpy()
+    meta.append(dict(key=key, d=39, alpha=1.5, scale=1.5, n_iter=50, ensure_sum_one=False))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "g6_entmax.npz")
+    np.savez_compressed(path, **out)
+    print(f"{'g6_entmax':42s} {os.path.getsize(path) / 1024:8.1f} KiB  {len(meta)} cases")
+
+
+def main():
+    # G1 — Frappe armnet_1h (BASELINE.json configs[0]) on real rows of data/frappe/test.libsvm
+    fid, fval = frappe_rows(64)
+    for regime in ("fresh", "stress"):
+        model_case(f"g1_frappe_1h_a1.7_{regime}", "1h", base(10, 5382, 10, 1.7, 10, mlp_nhid=64), 64, 11,
+                   regime, ids=fid, vals=fval)
+    # G2 — Criteo shape one-head (configs[1]) across alpha
+    for alpha in (1.0, 1.5, 1.7, 2.0, 2.5):
+        for regime in ("fresh", "stress"):
+            model_case(f"g2_criteo_1h_a{alpha}_{regime}", "1h", base(39, 512, 16, alpha, 32), 8, 21, regime)
+    model_case("g2_criteo_1h_a2.0_stress_mlp256", "1h", base(39, 512, 16, 2.0, 32, mlp_nhid=256), 8, 22, "stress")
+    # G3 — multi-head (configs[2])
+    for alpha in (1.7, 2.0):
+        for regime in ("fresh", "stress"):
+            model_case(f"g3_criteo_mh4_a{alpha}_{regime}", "mh", base(39, 512, 16, alpha, 32, nhead=4), 5, 31, regime)
+    # G4 — one-head nemb=64 (configs[3] shape)
+    for alpha in (1.7, 2.0):
+        model_case(f"g4_criteo_1h_e64_a{alpha}_stress", "1h", base(39, 256, 64, alpha, 32), 8, 41, "stress")
+    # G5 — Avazu shape + DNN ensemble (configs[4])
+    model_case("g5_avazu_mh4_ens_a1.7_stress", "mh",
+               base(22, 512, 32, 1.7, 32, nhead=4, ensemble=True), 5, 51, "stress")
+    model_case("g5_avazu_1h_ens_a2.0_fresh", "1h",
+               base(22, 512, 32, 2.0, 32, ensemble=True), 16, 52, "fresh")
+    # odd shapes: nfield not a multiple of 4, nhid not a multiple of 16, mlp_nlayer=0, B=1 (0-dim squeeze)
+    model_case("g7_odd_1h_f13_e12_h7_a1.5", "1h", base(13, 300, 12, 1.5, 7, mlp_nlayer=0), 33, 61, "stress")
+    model_case("g7_odd_mh3_f7_e8_h5_a2.0", "mh", base(7, 300, 8, 2.0, 5, nhead=3), 17, 62, "stress")
+    model_case("g7_b1_1h_a1.7", "1h", base(39, 512, 16, 1.7, 32), 1, 63, "stress",
+               ids=torch.randint(0, 512, (1, 39), generator=torch.Generator().manual_seed(5)),
+               vals=torch.rand(1, 39, generator=torch.Generator().manual_seed(6)))
+    # train mode (batch-statistics BN, armnet_1h.py:85 with nn.BatchNorm1d in training)
+    model_case("g8_train_1h_a1.7_stress", "1h", base(39, 512, 16, 1.7, 32), 32, 71, "stress", train=True)
+    entmax_cases()
+
+
+if __name__ == "__main__":
+    main()
