@@ -1,0 +1,102 @@
+"""Tensor-level wrappers over the C ABI: parameter folding cache + fused-block launch.
+
+PyTorch here is plumbing (device memory, streams); all arithmetic of the hot
+path runs in the HIP kernels.  CPU tensors are rejected — there is no fallback.
+"""
+import torch
+
+from . import native
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise native.ArmnetNativeError(
+            f"{what} is on {t.device}: the ARM-Net HIP path runs on the MI355X only (no CPU fallback). "
+            "Move the model and the batch to the GPU (model.cuda(), batch['id'].cuda(), ...).")
+
+
+class ArmBlockParams:
+    """Folded parameters of one ARM block (q_fold, bn_scale, bn_shift), refreshed when the
+    source tensors change (tracked by their autograd version counters and storage pointers)."""
+
+    def __init__(self):
+        self.key = None
+        self.q_fold = self.bn_scale = self.bn_shift = None
+
+    def get(self, variant, K, H, E, D, bilinear_w, query, bn):
+        src = (bilinear_w, query, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (variant, K, H, E, D, float(bn.eps))
+        if key != self.key:
+            dev = query.device
+            O = K * H
+            if self.q_fold is None or self.q_fold.shape != (O, E) or self.q_fold.device != dev:
+                self.q_fold = torch.empty(O, E, device=dev, dtype=torch.float32)
+                self.bn_scale = torch.empty(O, device=dev, dtype=torch.float32)
+                self.bn_shift = torch.empty(O, device=dev, dtype=torch.float32)
+            native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
+                               bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                               float(bn.eps), self.q_fold, self.bn_scale, self.bn_shift)
+            self.key = key
+        return self.q_fold, self.bn_scale, self.bn_shift
+
+
+def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
+                      write_clamped_vals=True, check_ids=True, flags=0, rows=None):
+    """Fused a2..a9.  Returns out [B, O, E] (post-BN).  ``vals`` is clamped in place
+    when write_clamped_vals (the reference's side effect, armnet_1h.py:81).  With check_ids an
+    out-of-range id raises IndexError like the reference's CPU path (costs one host sync)."""
+    _require_cuda(vals, "x['value']")
+    if not vals.is_contiguous() or vals.dtype != torch.float32:
+        raise native.ArmnetNativeError("x['value'] must be a contiguous float32 tensor (clamped in place)")
+    B, F = vals.shape
+    O, E = q_fold.shape
+    values2d = values.detach().reshape(O, F)
+    out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+    fl = flags | (native.F_WRITE_CLAMPED_VALS if write_clamped_vals else 0)
+    if rows is not None:
+        native.fused_fwd_from_rows(B, F, E, O, alpha, n_iter, fl, rows, vals, q_fold, values2d, bn_scale,
+                                   bn_shift, out)
+        return out
+    _require_cuda(ids, "x['id']")
+    ids = ids if ids.is_contiguous() else ids.contiguous()
+    status = torch.zeros(1, device=vals.device, dtype=torch.int32) if check_ids else None
+    native.fused_fwd(B, F, E, O, alpha, n_iter, fl, ids, vals, table.detach(), q_fold, values2d, bn_scale,
+                     bn_shift, out, status)
+    if check_ids and int(status.item()) != 0:
+        raise IndexError("index out of range in self")
+    return out
+
+
+def embedding_forward(ids, vals, table, check_ids=True):
+    """layers.py:15-21 — table[ids] * vals.unsqueeze(2) -> [B, F, E]."""
+    _require_cuda(ids, "x['id']")
+    shape = tuple(ids.shape)
+    E = table.shape[1]
+    ids_c = ids.contiguous()
+    n = ids_c.numel()
+    out = torch.empty(*shape, E, device=ids.device, dtype=torch.float32)
+    v = None
+    if vals is not None:
+        v = vals.contiguous()
+        if v.dtype != torch.float32:
+            v = v.float()
+    status = torch.zeros(1, device=ids.device, dtype=torch.int32) if check_ids else None
+    native.gather_scale(n, E, ids_c, v, table.detach(), out, status)
+    if check_ids and int(status.item()) != 0:
+        raise IndexError("index out of range in self")
+    return out
+
+
+def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0):
+    """utils/entmax.py:134 — alpha-entmax over `dim` (softmax when alpha == 1)."""
+    _require_cuda(X, "X")
+    if X.dtype != torch.float32:
+        raise native.ArmnetNativeError(f"entmax: float32 only, got {X.dtype}")
+    nd = X.dim()
+    dim = dim % nd
+    Xt = X.movedim(dim, -1).contiguous() if dim != nd - 1 else X.contiguous()
+    d = Xt.shape[-1]
+    P = torch.empty_like(Xt)
+    if Xt.numel():
+        native.entmax(Xt.numel() // d, d, float(alpha), n_iter, ensure_sum_one, flags, Xt, P)
+    return P.movedim(-1, dim) if dim != nd - 1 else P

@@ -1,0 +1,136 @@
+"""nn.Module plumbing shared by models/armnet.py and models/armnet_1h.py.
+
+The two public ARMNetModel classes keep the reference's constructor signatures,
+sub-module names and state_dict keys so weights move freely
+between the reference and this build; everything between the input dict and the
+MLP head's input runs in ONE fused HIP kernel (armnet_fused_fwd_f32).
+"""
+import torch
+import torch.nn as nn
+
+from . import native
+from .block import ArmBlockParams, _require_cuda, arm_block_forward, embedding_forward, entmax_forward
+
+
+class HipEmbedding(nn.Module):
+    """Field embedding lookup scaled by the field value (reference: models/layers.py:8-21).
+
+    forward(x) with x = {'id': Long[B,F], 'value': Float[B,F]} -> Float[B,F,E] computed by
+    armnet_gather_scale_f32.  The parameter lives at ``embedding.weight`` like the reference's."""
+
+    def __init__(self, nfeat, nemb):
+        super().__init__()
+        self.embedding = nn.Embedding(nfeat, nemb)
+        nn.init.xavier_uniform_(self.embedding.weight)
+        self.check_ids = True
+
+    def forward(self, x):
+        return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=self.check_ids)
+
+
+def build_mlp(ninput, nlayers, nhid, dropout, noutput=1):
+    """Prediction head (reference: models/layers.py:68-88): nlayers x (Linear, BatchNorm1d, ReLU,
+    Dropout) then Linear(., noutput); with nlayers == 0 a single Linear(ninput, noutput)."""
+    stack = []
+    width = ninput
+    for _ in range(nlayers):
+        stack += [nn.Linear(width, nhid), nn.BatchNorm1d(nhid), nn.ReLU(), nn.Dropout(p=dropout)]
+        width = nhid
+    stack.append(nn.Linear(width, noutput))
+    return nn.Sequential(*stack)
+
+
+class SparseGateBase(nn.Module):
+    """Owner of the attention parameters (bilinear_w, query, values) of one ARM block.
+
+    Calling it on x [B,F,E] returns the per-field value weights (armnet_1h.py:25-34 /
+    armnet.py:26-36): gates by a dense contraction, the sparse map by armnet_entmax_f32.  The model
+    forward does NOT go through here — it uses the fused kernel — this is the stand-alone surface."""
+
+    alpha: float
+    n_iter = 50
+
+    def _gates(self, x):
+        raise NotImplementedError
+
+    def forward(self, x):
+        gates = self._gates(x)
+        p = entmax_forward(gates, self.alpha, dim=-1, n_iter=self.n_iter)
+        return p * self.values
+
+
+class ArmNetBase(nn.Module):
+    """Common forward of both ARM-Net variants."""
+
+    variant = native.ONE_HEAD
+
+    def _init_common(self, nfield, nfeat, nemb, nhead, nhid, alpha, mlp_nlayer, mlp_nhid, dropout, ensemble,
+                     deep_nlayer, deep_nhid, noutput, attn_layer):
+        # construction order == the reference's (armnet_1h.py:59-74): same seed -> same initial weights
+        self.nfield, self.nfeat, self.nemb = nfield, nfeat, nemb
+        self.nhead, self.nhid, self.alpha = nhead, nhid, float(alpha)
+        self.embedding = HipEmbedding(nfeat, nemb)
+        self.attn_layer = attn_layer()
+        self.arm_bn = nn.BatchNorm1d(nhead * nhid)
+        self.mlp = _MLP(nhead * nhid * nemb, mlp_nlayer, mlp_nhid, dropout, noutput=noutput)
+        if ensemble:
+            self.deep_embedding = HipEmbedding(nfeat, nemb)
+            self.deep_mlp = _MLP(nfield * nemb, deep_nlayer, deep_nhid, dropout, noutput=noutput)
+            self.ensemble_layer = nn.Linear(2 * noutput, noutput)
+            nn.init.constant_(self.ensemble_layer.weight, 0.5)
+            nn.init.constant_(self.ensemble_layer.bias, 0.0)
+        self._folded = ArmBlockParams()
+        self.check_ids = True          # IndexError on out-of-range ids (one host sync per call)
+        self.n_iter = 50               # utils/entmax.py:239 default, never overridden by the reference
+        self.kernel_flags = 0          # native.F_* bits for testing (faithful bisection, generic kernel)
+
+    # -- the fused block ------------------------------------------------------------------------
+    def _d_k(self):
+        raise NotImplementedError
+
+    def arm_block(self, ids, vals):
+        """ids [B,F], vals [B,F] (clamped in place) -> post-BN exponential neurons [B, O, E]."""
+        if self.training:
+            raise NotImplementedError(
+                "ARMNetModel (HIP): the training pass (batch-statistics BatchNorm + backward of the fused "
+                "block, SURVEY.md §8f-2) is not built yet; call model.eval().")
+        _require_cuda(vals, "x['value']")
+        _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
+        at = self.attn_layer
+        bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
+        qf, sc, sh = self._folded.get(self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), bw, at.query,
+                                      self.arm_bn)
+        return arm_block_forward(ids, vals, self.embedding.embedding.weight, qf, at.values, sc, sh, self.alpha,
+                                 n_iter=self.n_iter, write_clamped_vals=True, check_ids=self.check_ids,
+                                 flags=self.kernel_flags)
+
+    def forward(self, x, vals=None):
+        """x = {'id': Long[B,F], 'value': Float[B,F], ...} -> logits Float[B] (armnet_1h.py:76-98).
+        Also accepts forward(ids, vals).  x['value'] is clamped to [1e-3, 1] IN PLACE."""
+        if vals is not None:
+            x = {"id": x, "value": vals}
+        ids, v = x["id"], x["value"]
+        if v.dtype != torch.float32:
+            raise native.ArmnetNativeError(f"x['value'] must be float32, got {v.dtype}")
+        v_run = v if v.is_contiguous() else v.contiguous()
+        x_arm = self.arm_block(ids, v_run)                       # [B, O, E]
+        if v_run is not v:
+            v.copy_(v_run)                                       # keep the visible clamp side effect
+        y = self.mlp(x_arm.view(x_arm.shape[0], -1))            # [B, noutput]
+        if hasattr(self, "ensemble_layer"):
+            self.deep_embedding.check_ids = False                # ids were validated by the fused call
+            x_deep = self.deep_embedding({"id": ids, "value": v})  # sees the clamped values (armnet.py:94)
+            y_deep = self.deep_mlp(x_deep.view(x_deep.shape[0], -1))
+            y = self.ensemble_layer(torch.cat([y, y_deep], dim=1))
+        return y.squeeze()
+
+
+class _MLP(nn.Module):
+    """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*)."""
+
+    def __init__(self, ninput, nlayers, nhid, dropout, noutput=1):
+        super().__init__()
+        self.mlp = build_mlp(ninput, nlayers, nhid, dropout, noutput)
+
+    def forward(self, x):
+        return self.mlp(x)

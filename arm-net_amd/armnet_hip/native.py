@@ -1,0 +1,154 @@
+"""ctypes binding of libarmnet_hip.so (the C ABI declared in include/armnet_hip.h).
+
+There is NO CPU fallback here: if the HIP library cannot be loaded the import of
+the product path fails loudly.  Tensors are passed as raw device pointers and
+the current torch HIP stream; PyTorch is used only for memory and streams.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG, "lib", "libarmnet_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+ABI_VERSION = 1
+
+OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
+ID_I64, ID_I32 = 0, 1
+ONE_HEAD, MULTI_HEAD = 0, 1
+F_WRITE_CLAMPED_VALS, F_FAITHFUL_BISECT, F_FORCE_GENERIC = 0x1, 0x2, 0x4
+
+EXPORTS = (
+    "armnet_abi_version", "armnet_strerror", "armnet_last_hip_error", "armnet_fold_params_f32",
+    "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
+    "armnet_clamp_vals_f32", "armnet_entmax_f32",
+)
+
+_lib = None
+
+
+class ArmnetNativeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile arm-net_amd/csrc for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library or raise.  Never substitutes anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ArmnetNativeError(
+            f"{LIB_PATH} is missing: the ARM-Net HIP kernels are not built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {CSRC}`). "
+            "There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise ArmnetNativeError(f"{LIB_PATH} does not export {name}")
+    lib.armnet_strerror.restype = ctypes.c_char_p
+    lib.armnet_last_hip_error.restype = ctypes.c_char_p
+    if lib.armnet_abi_version() != ABI_VERSION:
+        raise ArmnetNativeError(f"ABI version mismatch: library {lib.armnet_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    lib = load()
+    msg = lib.armnet_strerror(rc).decode()
+    if rc == ERR_HIP:
+        msg += ": " + lib.armnet_last_hip_error().decode()
+    if rc == ERR_ID_RANGE:
+        raise IndexError(msg)
+    raise ArmnetNativeError(f"armnet_hip call failed ({rc}): {msg}")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ArmnetNativeError(f"{name}: expected a contiguous float32 tensor on the HIP device, got "
+                                f"{t.dtype} on {t.device} (contiguous={t.is_contiguous()})")
+    return t
+
+
+def _id_type(ids):
+    if ids.dtype == torch.int64:
+        return ID_I64
+    if ids.dtype == torch.int32:
+        return ID_I32
+    raise ArmnetNativeError(f"ids must be int64 or int32, got {ids.dtype}")
+
+
+def fold_params(variant, K, H, E, D, bilinear_w, query, bn_w, bn_b, bn_mean, bn_var, eps,
+                q_fold, bn_scale, bn_shift):
+    for n, t in (("bilinear_w", bilinear_w), ("query", query), ("bn_w", bn_w), ("bn_b", bn_b),
+                 ("bn_mean", bn_mean), ("bn_var", bn_var), ("q_fold", q_fold), ("bn_scale", bn_scale),
+                 ("bn_shift", bn_shift)):
+        _dev_f32(t, n)
+    check(load().armnet_fold_params_f32(variant, K, H, E, D, _ptr(bilinear_w), _ptr(query), _ptr(bn_w),
+                                        _ptr(bn_b), _ptr(bn_mean), _ptr(bn_var), ctypes.c_float(eps),
+                                        _ptr(q_fold), _ptr(bn_scale), _ptr(bn_shift), _stream()))
+
+
+def fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, bn_scale, bn_shift, out,
+              id_status=None):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values),
+                 ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("out", out)):
+        _dev_f32(t, n)
+    check(load().armnet_fused_fwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                      ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                      ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values),
+                                      _ptr(bn_scale), _ptr(bn_shift), _ptr(out), _ptr(id_status), _stream()))
+
+
+def fused_fwd_from_rows(B, F, E, O, alpha, n_iter, flags, rows, vals, q_fold, values, bn_scale, bn_shift, out):
+    for n, t in (("rows", rows), ("vals", vals), ("q_fold", q_fold), ("values", values),
+                 ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("out", out)):
+        _dev_f32(t, n)
+    check(load().armnet_fused_fwd_from_rows_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                                ctypes.c_uint32(flags), _ptr(rows), _ptr(vals), _ptr(q_fold),
+                                                _ptr(values), _ptr(bn_scale), _ptr(bn_shift), _ptr(out),
+                                                _stream()))
+
+
+def gather_scale(n_rows, E, ids, vals, table, out, id_status=None):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    _dev_f32(table, "table"); _dev_f32(out, "out")
+    if vals is not None:
+        _dev_f32(vals, "vals")
+    check(load().armnet_gather_scale_f32(ctypes.c_int64(n_rows), E, _ptr(ids), _id_type(ids), _ptr(vals),
+                                         _ptr(table), ctypes.c_int64(table.shape[0]), _ptr(out),
+                                         _ptr(id_status), _stream()))
+
+
+def clamp_vals(vals):
+    _dev_f32(vals, "vals")
+    check(load().armnet_clamp_vals_f32(_ptr(vals), ctypes.c_int64(vals.numel()), _stream()))
+
+
+def entmax(rows, d, alpha, n_iter, ensure_sum_one, flags, X, P):
+    _dev_f32(X, "X"); _dev_f32(P, "P")
+    check(load().armnet_entmax_f32(ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
+                                   int(bool(ensure_sum_one)), ctypes.c_uint32(flags), _ptr(X), _ptr(P), _stream()))

@@ -1,0 +1,248 @@
+// armnet_common.h — shared host/device helpers for the ARM-Net HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/armnet_hip.h"
+
+namespace armnet {
+
+// ---- sparse-map solver selection (host side fills this, kernels take it by value) ------------
+enum SolverMode : int {
+    SOLVE_SOFTMAX = 0,   // alpha == 1: nn.Softmax(dim=-1)                    (armnet_1h.py:12)
+    SOLVE_BISECT = 1,    // the reference's n_iter-step bisection, literally   (entmax.py:29-68)
+    SOLVE_NEWTON = 2,    // 1 < alpha < 2: Newton from the left on the same root
+    SOLVE_MICHELOT = 3,  // alpha == 2: Newton == Michelot's finite algorithm
+    SOLVE_NEWTON15 = 4   // alpha == 1.5: Newton with p = t*t (no transcendental)
+};
+
+struct SparseMapCfg {
+    int mode;
+    int n_iter;          // bisection steps (SOLVE_BISECT)
+    int ensure_sum_one;
+    float am1;           // alpha - 1            (fp32, entmax.py:42)
+    float r;             // 1 / (alpha - 1)      (fp32, entmax.py:22)
+    float tau_hi_off;    // (1/d) ** (alpha - 1) (entmax.py:47), also the mean-start offset
+};
+
+// Host: choose the solver the way armnet_hip.h documents.
+inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_sum_one, uint32_t flags) {
+    SparseMapCfg c;
+    c.n_iter = n_iter;
+    c.ensure_sum_one = ensure_sum_one;
+    c.am1 = alpha - 1.0f;
+    c.r = 1.0f / c.am1;
+    c.tau_hi_off = powf((float)(1.0 / (double)d), c.am1);
+    if (alpha == 1.0f) {
+        c.mode = SOLVE_SOFTMAX;
+    } else if ((flags & ARMNET_F_FAITHFUL_BISECT) || alpha > 2.0f || alpha < 1.0f || n_iter < 24 || !ensure_sum_one) {
+        c.mode = SOLVE_BISECT;
+    } else if (alpha == 2.0f) {
+        c.mode = SOLVE_MICHELOT;
+    } else if (alpha == 1.5f) {
+        c.mode = SOLVE_NEWTON15;
+    } else {
+        c.mode = SOLVE_NEWTON;
+    }
+    return c;
+}
+
+constexpr int kNewtonMaxIter = 40;
+constexpr float kNewtonTol = 2e-7f;   // stop once sum(p) - 1 <= tol (a few fp32 ulps of 1)
+
+// thread-local record of the last HIP failure (armnet_last_hip_error)
+void set_hip_error(hipError_t e, const char* where);
+
+#define ARMNET_HIP_TRY(expr)                                   \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) {                                \
+            ::armnet::set_hip_error(_e, #expr);                \
+            return ARMNET_ERR_HIP;                             \
+        }                                                      \
+    } while (0)
+
+#define ARMNET_LAUNCH_CHECK()                                  \
+    do {                                                       \
+        hipError_t _e = hipGetLastError();                     \
+        if (_e != hipSuccess) {                                \
+            ::armnet::set_hip_error(_e, "kernel launch");      \
+            return ARMNET_ERR_HIP;                             \
+        }                                                      \
+    } while (0)
+
+#if defined(__HIPCC__)
+// ---- device helpers ---------------------------------------------------------------------------
+
+// torch.clamp(min=0) semantics: NaN stays NaN (fmaxf would drop it)
+__device__ __forceinline__ float clamp_min0(float x) { return x > 0.f ? x : (x != x ? x : 0.f); }
+
+// x['value'].clamp_(1e-3, 1.) — NaN stays NaN
+__device__ __forceinline__ float clamp_val(float v) {
+    v = v < 1e-3f ? 1e-3f : v;
+    v = v > 1.0f ? 1.0f : v;
+    return v;
+}
+
+// exp with ~1 ulp error from the hardware exp2: exp(z) = 2^(z*log2e), product carried in two terms
+__device__ __forceinline__ float exp_accurate(float z) {
+    const float L2E_HI = 1.44269502162933349609375f;      // fp32(log2(e))
+    const float L2E_LO = 1.92596299112661746e-08f;        // log2(e) - L2E_HI
+    const float LN2 = 0.693147182464599609375f;
+    float t = z * L2E_HI;
+    float lo = fmaf(z, L2E_HI, -t);
+    lo = fmaf(z, L2E_LO, lo);
+    float e = __builtin_amdgcn_exp2f(t);
+    float corr = fmaf(e, lo * LN2, e);
+    return (e < INFINITY && e > 0.f) ? corr : e;          // keep inf / 0 / NaN untouched
+}
+
+// t ** pw for t > 0 through the hardware log2/exp2 pair (Newton solver only; ~2 ulp)
+__device__ __forceinline__ float pow_pos(float t, float pw) {
+    return __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(t));
+}
+
+// In-place sparse map of ONE row held by ONE thread at x[0], x[stride], ... x[(d-1)*stride]
+// (LDS column or global row).  Semantics: entmax.py:29-68 / nn.Softmax; see SolverMode.
+__device__ inline void sparse_map_row(float* x, int stride, int d, const SparseMapCfg& c) {
+    if (c.mode == SOLVE_SOFTMAX) {
+        float mx = -INFINITY;
+        bool nan = false;
+        for (int i = 0; i < d; ++i) { float v = x[i * stride]; nan |= (v != v); mx = fmaxf(mx, v); }
+        float s = 0.f;
+        for (int i = 0; i < d; ++i) { float e = expf(x[i * stride] - mx); x[i * stride] = e; s += e; }
+        if (nan) s = NAN;
+        for (int i = 0; i < d; ++i) x[i * stride] = x[i * stride] / s;
+        return;
+    }
+    // entmax.py:42,44
+    float mx = -INFINITY, sum = 0.f;
+    for (int i = 0; i < d; ++i) {
+        float v = x[i * stride] * c.am1;
+        x[i * stride] = v;
+        mx = fmaxf(mx, v);
+        sum += v;
+    }
+    const bool poisoned = !(mx < INFINITY) || (sum != sum);   // +inf or NaN anywhere -> NaN row (torch.max/clamp)
+    if (c.mode == SOLVE_BISECT) {
+        if (poisoned) mx = NAN;
+        float tau_lo = mx - 1.0f;                 // entmax.py:46
+        const float tau_hi = mx - c.tau_hi_off;   // entmax.py:47
+        float f_lo = 0.f;                         // entmax.py:49
+        for (int i = 0; i < d; ++i) f_lo += powf(clamp_min0(x[i * stride] - tau_lo), c.r);
+        f_lo -= 1.0f;
+        float dm = tau_hi - tau_lo;               // entmax.py:51
+        float tau_m = tau_lo;
+        for (int it = 0; it < c.n_iter; ++it) {   // entmax.py:53-61
+            dm *= 0.5f;
+            tau_m = tau_lo + dm;
+            float s = 0.f;
+            for (int i = 0; i < d; ++i) s += powf(clamp_min0(x[i * stride] - tau_m), c.r);
+            const float f_m = s - 1.0f;
+            if (f_m * f_lo >= 0.f) tau_lo = tau_m;
+        }
+        float s = 0.f;                            // p_m of the LAST tau_m, entmax.py:57,63-64
+        for (int i = 0; i < d; ++i) {
+            float p = powf(clamp_min0(x[i * stride] - tau_m), c.r);
+            x[i * stride] = p;
+            s += p;
+        }
+        if (c.ensure_sum_one)
+            for (int i = 0; i < d; ++i) x[i * stride] = x[i * stride] / s;
+        return;
+    }
+    // Newton from the left: tau0 is the larger of two lower bounds of the root,
+    //   mx - 1 (p_max <= 1) and mean - d^-(alpha-1) (power-mean inequality, r >= 1).
+    float tau = fmaxf(mx - 1.0f, sum / (float)d - c.tau_hi_off);
+    if (poisoned) tau = NAN;
+    const float rm1 = c.r - 1.0f;
+    for (int it = 0; it < kNewtonMaxIter; ++it) {
+        float S = 0.f, Dv = 0.f;
+        if (c.mode == SOLVE_MICHELOT) {
+            for (int i = 0; i < d; ++i) { float t = fmaxf(x[i * stride] - tau, 0.f); S += t; Dv += (t > 0.f) ? 1.f : 0.f; }
+        } else if (c.mode == SOLVE_NEWTON15) {
+            for (int i = 0; i < d; ++i) { float t = fmaxf(x[i * stride] - tau, 0.f); S = fmaf(t, t, S); Dv += t; }
+            Dv *= 2.0f;
+        } else {
+            for (int i = 0; i < d; ++i) {
+                float t = fmaxf(x[i * stride] - tau, 0.f);
+                float u = t > 0.f ? pow_pos(t, rm1) : 0.f;
+                S = fmaf(u, t, S);
+                Dv += u;
+            }
+            Dv *= c.r;
+        }
+        const float f = S - 1.0f;
+        if (!(f > kNewtonTol)) break;
+        const float tn = tau + f / Dv;
+        if (!(tn > tau)) break;
+        tau = tn;
+    }
+    float s = 0.f;
+    for (int i = 0; i < d; ++i) {
+        float t = fmaxf(x[i * stride] - tau, 0.f);
+        float p;
+        if (c.mode == SOLVE_MICHELOT) p = t;
+        else if (c.mode == SOLVE_NEWTON15) p = t * t;
+        else p = t > 0.f ? pow_pos(t, c.r) : 0.f;
+        x[i * stride] = p;
+        s += p;
+    }
+    if (tau != tau) s = NAN;
+    if (c.ensure_sum_one)
+        for (int i = 0; i < d; ++i) x[i * stride] = x[i * stride] / s;
+    else if (tau != tau)
+        for (int i = 0; i < d; ++i) x[i * stride] = NAN;
+}
+
+// 64-bit id load (low word used; high word only for the range check)
+template <typename IdT>
+__device__ __forceinline__ uint32_t load_id_checked(const IdT* p, int64_t nfeat, bool& bad) {
+    if constexpr (sizeof(IdT) == 8) {
+        const uint64_t v = (uint64_t)*p;
+        bad = v >= (uint64_t)nfeat;
+        return bad ? 0u : (uint32_t)v;
+    } else {
+        const uint32_t v = (uint32_t)*p;
+        bad = v >= (uint64_t)nfeat;
+        return bad ? 0u : v;
+    }
+}
+#endif  // __HIPCC__
+
+// ---- kernel launchers implemented in the .hip files (host-callable) ---------------------------
+int launch_fold_params(int variant, int K, int H, int E, int D, const float* bw, const float* q,
+                       const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v, float eps,
+                       float* q_fold, float* bn_scale, float* bn_shift, hipStream_t s);
+
+struct FusedArgs {
+    int64_t B;
+    int F, E, O;
+    const void* ids;      // [B,F] or null when rows != null
+    int id_type;
+    const float* rows;    // [B,F,E] pre-gathered unscaled rows, or null
+    float* vals;          // [B,F]
+    const float* table;
+    int64_t nfeat;
+    const float* q_fold;  // [O,E]
+    const float* values;  // [O,F]
+    const float* bn_scale;
+    const float* bn_shift;
+    float* out;           // [B,O,E]
+    int32_t* id_status;
+    uint32_t flags;
+    SparseMapCfg cfg;
+};
+
+int launch_fused_generic(const FusedArgs& a, hipStream_t s);
+// returns ARMNET_ERR_UNSUPPORTED when the shape has no MFMA specialisation
+int launch_fused_mfma(const FusedArgs& a, hipStream_t s);
+bool fused_mfma_supports(int F, int E, int O);
+
+int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
+                        const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s);
+int launch_clamp_vals(float* vals, int64_t n, hipStream_t s);
+int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, float* P, hipStream_t s);
+
+}  // namespace armnet

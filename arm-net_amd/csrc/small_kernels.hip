@@ -1,0 +1,176 @@
+// small_kernels.hip — parameter fold, gather*value, clamp, stand-alone sparse map.  gfx950.
+#include "armnet_common.h"
+
+namespace armnet {
+
+// ---------------------------------------------------------------------------------------------
+// Parameter fold (armnet_hip.h: armnet_fold_params_f32).  One thread per output element; the
+// contraction runs in double so that the fold adds no rounding of its own beyond the final cast.
+//   one-head   q_fold[o,e]     = D^-0.5 * sum_d query[o,d] * W[d,e]          (armnet_1h.py:30-32)
+//   multi-head q_fold[k*H+o,e] = D^-0.5 * sum_y bw[k,e,y] * query[k,o,y]     (armnet.py:33-34)
+__global__ void fold_params_kernel(int variant, int K, int H, int E, int D, const float* __restrict__ bw,
+                                   const float* __restrict__ q, const float* __restrict__ bn_w,
+                                   const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                   const float* __restrict__ bn_v, float eps, float* __restrict__ q_fold,
+                                   float* __restrict__ bn_scale, float* __restrict__ bn_shift) {
+    const int O = K * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < O * E) {
+        const int row = i / E, e = i % E;
+        const int k = row / H, o = row % H;
+        double acc = 0.0;
+        if (variant == ARMNET_ONE_HEAD) {
+            for (int d = 0; d < D; ++d) acc += (double)q[o * D + d] * (double)bw[d * E + e];
+        } else {
+            for (int y = 0; y < D; ++y)
+                acc += (double)bw[((size_t)k * E + e) * D + y] * (double)q[((size_t)k * H + o) * D + y];
+        }
+        const float scale = (float)(1.0 / sqrt((double)D));   // python: d_k ** -0.5, cast to fp32 by the tensor multiply
+        q_fold[i] = (float)(acc * (double)scale);
+    }
+    if (i < O) {
+        // ATen's eval-mode transform: alpha = w * 1/sqrt(var + eps); beta = b - mean * alpha  (fp32)
+        const float invstd = 1.0f / sqrtf(bn_v[i] + eps);
+        const float a = bn_w[i] * invstd;
+        bn_scale[i] = a;
+        bn_shift[i] = bn_b[i] - bn_m[i] * a;
+    }
+}
+
+int launch_fold_params(int variant, int K, int H, int E, int D, const float* bw, const float* q,
+                       const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v, float eps,
+                       float* q_fold, float* bn_scale, float* bn_shift, hipStream_t s) {
+    const int n = K * H * E;
+    const int block = 256;
+    fold_params_kernel<<<(n + block - 1) / block, block, 0, s>>>(variant, K, H, E, D, bw, q, bn_w, bn_b, bn_m,
+                                                                  bn_v, eps, q_fold, bn_scale, bn_shift);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding.forward alone (layers.py:20-21): out[r,:] = table[ids[r],:] * vals[r].
+// One lane per 16-byte chunk when E % 4 == 0 (adjacent lanes share a row -> one 64..256 B segment
+// per row), scalar lanes otherwise.
+template <typename IdT, int VEC>
+__global__ void gather_scale_kernel(int64_t n_rows, int E, const IdT* __restrict__ ids,
+                                    const float* __restrict__ vals, const float* __restrict__ table,
+                                    int64_t nfeat, float* __restrict__ out, int32_t* id_status) {
+    const int cpr = E / VEC;  // chunks per row
+    const int64_t total = n_rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr);
+        bool bad;
+        const uint32_t id = load_id_checked(ids + r, nfeat, bad);
+        if (bad && id_status) atomicOr(id_status, 1);
+        const float v = vals ? vals[r] : 1.0f;
+        const float* src = table + (size_t)id * E + c * VEC;
+        float* dst = out + r * E + c * VEC;
+        if constexpr (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(src);
+            t.x *= v; t.y *= v; t.z *= v; t.w *= v;
+            *reinterpret_cast<float4*>(dst) = t;
+        } else {
+            dst[0] = src[0] * v;
+        }
+    }
+}
+
+int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
+                        const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s) {
+    if (n_rows == 0) return ARMNET_OK;
+    const bool vec = (E % 4 == 0) && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const int64_t total = n_rows * (vec ? E / 4 : E);
+    const int block = 256;
+    int64_t grid = (total + block - 1) / block;
+    if (grid > 256 * 16) grid = 256 * 16;
+#define GS(IdT, V)                                                                                          \
+    gather_scale_kernel<IdT, V><<<(int)grid, block, 0, s>>>(n_rows, E, (const IdT*)ids, vals, table, nfeat, \
+                                                            out, id_status)
+    if (id_type == ARMNET_ID_I64) { if (vec) GS(int64_t, 4); else GS(int64_t, 1); }
+    else { if (vec) GS(int32_t, 4); else GS(int32_t, 1); }
+#undef GS
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+__global__ void clamp_vals_kernel(float* vals, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        vals[i] = clamp_val(vals[i]);
+}
+
+int launch_clamp_vals(float* vals, int64_t n, hipStream_t s) {
+    if (n == 0) return ARMNET_OK;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    clamp_vals_kernel<<<(int)grid, 256, 0, s>>>(vals, n);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone sparse map over the last dim of [rows, d] (utils/entmax.py:134).
+// A block owns TPB consecutive rows = one contiguous span of TPB*d floats: it is read coalesced,
+// transposed through LDS so that thread r owns row r as the LDS column  lds[i*(TPB+1) + r]
+// (odd stride: conflict-free both for the transposing writes and the per-thread column reads).
+template <int TPB>
+__global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ X,
+                                  float* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = TPB + 1;
+    for (int64_t r0 = (int64_t)blockIdx.x * TPB; r0 < rows; r0 += (int64_t)gridDim.x * TPB) {
+        const int nr = (int)((rows - r0) < TPB ? (rows - r0) : TPB);
+        const int n = nr * d;
+        const float* src = X + r0 * d;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += TPB) {
+            const int r = k / d, i = k - r * d;
+            lds[i * S + r] = src[k];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nr) sparse_map_row(lds + threadIdx.x, S, d, cfg);
+        __syncthreads();
+        float* dst = P + r0 * d;
+        for (int k = threadIdx.x; k < n; k += TPB) {
+            const int r = k / d, i = k - r * d;
+            dst[k] = lds[i * S + r];
+        }
+    }
+}
+
+// Fallback for very long rows: one thread per row, in place in global memory.
+__global__ void entmax_global_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ X,
+                                     float* __restrict__ P) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        float* p = P + r * d;
+        const float* x = X + r * d;
+        for (int i = 0; i < d; ++i) p[i] = x[i];
+        sparse_map_row(p, 1, d, cfg);
+    }
+}
+
+int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, float* P, hipStream_t s) {
+    if (rows == 0) return ARMNET_OK;
+    const size_t lds128 = (size_t)d * 129 * sizeof(float);
+    const size_t lds64 = (size_t)d * 65 * sizeof(float);
+    if (lds128 <= 64 * 1024) {
+        int64_t grid = (rows + 127) / 128;
+        if (grid > 256 * 8) grid = 256 * 8;
+        entmax_lds_kernel<128><<<(int)grid, 128, lds128, s>>>(rows, d, cfg, X, P);
+    } else if (lds64 <= 64 * 1024) {
+        int64_t grid = (rows + 63) / 64;
+        if (grid > 256 * 8) grid = 256 * 8;
+        entmax_lds_kernel<64><<<(int)grid, 64, lds64, s>>>(rows, d, cfg, X, P);
+    } else {
+        int64_t grid = (rows + 63) / 64;
+        if (grid > 4096) grid = 4096;
+        entmax_global_kernel<<<(int)grid, 64, 0, s>>>(rows, d, cfg, X, P);
+    }
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+}  // namespace armnet

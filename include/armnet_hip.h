@@ -1,0 +1,131 @@
+/*
+ * armnet_hip.h — C ABI of the MI355X-native ARM-Net forward hot path.
+ *
+ * The reference (nusdbsystem/ARM-Net) has no FFI layer: its hot path is a chain
+ * of ATen calls made from two nn.Modules.  The entry points below are what a
+ * binding of that path replaces; each cites the reference lines it stands for.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t
+ *     passed as void* (NULL = the null stream).
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller
+ *     owns all memory; nothing is retained after return.
+ *   - calls enqueue work on `stream` and return without synchronising.
+ *   - return value: 0 = ARMNET_OK, negative = armnet_status; never throws, never exits.
+ *   - re-entrant; no global mutable state (the last HIP error string is thread-local).
+ *   - all floating point is IEEE fp32; tensors are dense row-major.
+ *
+ * Shapes: B batch, F nfield, E nemb, O = nhead * nhid exponential neurons
+ * (one-head model: nhead = 1), D = d_k.
+ */
+#ifndef ARMNET_HIP_H
+#define ARMNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARMNET_ABI_VERSION 1
+
+typedef enum armnet_status {
+    ARMNET_OK = 0,
+    ARMNET_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, misaligned buffer */
+    ARMNET_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover (see armnet_strerror) */
+    ARMNET_ERR_ID_RANGE = -3,     /* reserved for host-side checked wrappers (IndexError) */
+    ARMNET_ERR_HIP = -4           /* a HIP runtime call failed: see armnet_last_hip_error() */
+} armnet_status;
+
+/* ids may be int64 (torch.LongTensor, data_loader.py:20) or int32 */
+typedef enum armnet_id_type { ARMNET_ID_I64 = 0, ARMNET_ID_I32 = 1 } armnet_id_type;
+
+/* model variant for parameter folding */
+typedef enum armnet_variant {
+    ARMNET_ONE_HEAD = 0,  /* models/armnet_1h.py: bilinear_w is nn.Linear weight [D,E], query [H,D] */
+    ARMNET_MULTI_HEAD = 1 /* models/armnet.py:    bilinear_w [K,E,D], query [K,H,D] */
+} armnet_variant;
+
+/* flags for the fused forward */
+#define ARMNET_F_WRITE_CLAMPED_VALS 0x1u /* reproduce x['value'].clamp_() on the caller's buffer */
+#define ARMNET_F_FAITHFUL_BISECT    0x2u /* run the reference's n_iter-step bisection literally */
+#define ARMNET_F_FORCE_GENERIC      0x4u /* bypass the MFMA-specialised kernel (testing) */
+
+int armnet_abi_version(void);
+const char* armnet_strerror(int status);
+const char* armnet_last_hip_error(void);
+
+/*
+ * Parameter-only precompute (re-run when weights change).  Replaces nothing the
+ * reference executes per batch; it folds, exactly in real arithmetic,
+ *   - the key projection into the query (models/armnet_1h.py:30-32, models/armnet.py:33-34):
+ *       q_fold[k*H+o, e] = D^-0.5 * sum_y W[k][e,y] * query[k][o,y]
+ *   - eval-mode BatchNorm1d into an affine (models/armnet_1h.py:65,85, models/armnet.py:67,89):
+ *       bn_scale[c] = weight[c] / sqrt(running_var[c] + eps);  bn_shift[c] = bias[c] - running_mean[c] * bn_scale[c]
+ * Outputs: q_fold [K*H, E], bn_scale [K*H], bn_shift [K*H].
+ */
+int armnet_fold_params_f32(int variant, int K, int H, int E, int D,
+                           const float* bilinear_w, const float* query,
+                           const float* bn_weight, const float* bn_bias,
+                           const float* bn_running_mean, const float* bn_running_var, float bn_eps,
+                           float* q_fold, float* bn_scale, float* bn_shift, void* stream);
+
+/*
+ * The fused block, rows a2..a9 of SURVEY.md §8(a), eval mode:
+ *   vals <- clamp(vals, 1e-3, 1)                         armnet_1h.py:81   / armnet.py:82
+ *   x[b,f,:] = table[ids[b,f],:] * vals[b,f]             layers.py:20-21
+ *   g[b,o,f] = sum_e x[b,f,e] * q_fold[o,e]              armnet_1h.py:30-32 / armnet.py:33-34 (folded)
+ *   p[b,o,:] = entmax_alpha(g[b,o,:])  (softmax if alpha == 1)   entmax.py:29-68, armnet_1h.py:12,33
+ *   w[b,o,f] = p[b,o,f] * values[o,f]                    armnet_1h.py:34   / armnet.py:36
+ *   z[b,o,:] = exp(sum_f w[b,o,f] * x[b,f,:])            armnet_1h.py:85-86 / armnet.py:86-87
+ *   out[b,o,:] = z[b,o,:] * bn_scale[o] + bn_shift[o]    armnet_1h.py:85   / armnet.py:88-89
+ * out is [B, O, E]; viewed as [B, O*E] it is the MLP head's input (armnet_1h.py:87-89).
+ *
+ * ids: [B,F] of `id_type`; vals: [B,F] (read; written only with ARMNET_F_WRITE_CLAMPED_VALS);
+ * table: [nfeat,E]; values: [O,F].  n_iter is the reference's bisection count (default 50): with
+ * n_iter >= 24 and alpha <= 2 a converged Newton/Michelot solve of the same root is used unless
+ * ARMNET_F_FAITHFUL_BISECT is set.
+ * id_status: optional device int32; bit 0 is OR-ed in when any id is outside [0,nfeat)
+ * (such ids read row 0 instead of faulting).  The host wrapper turns it into IndexError.
+ */
+int armnet_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                         const void* ids, int id_type, float* vals,
+                         const float* table, int64_t nfeat,
+                         const float* q_fold, const float* values,
+                         const float* bn_scale, const float* bn_shift,
+                         float* out, int32_t* id_status, void* stream);
+
+/*
+ * Same block fed with pre-gathered, UNSCALED rows [B,F,E] (the receiver side of the row-sharded
+ * lookup: rows arrive by all-to-all, DESIGN.md "multi-GPU").  vals as above.
+ */
+int armnet_fused_fwd_from_rows_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                                   const float* rows, float* vals,
+                                   const float* q_fold, const float* values,
+                                   const float* bn_scale, const float* bn_shift,
+                                   float* out, void* stream);
+
+/*
+ * models/layers.py:15-21 alone — Embedding.forward: out[b,f,:] = table[ids[b,f],:] * vals[b,f].
+ * Used for the ensemble branch's second table (armnet_1h.py:91, armnet.py:94).  vals may be NULL
+ * (plain gather, the owner side of the sharded lookup).  No clamp is applied here.
+ */
+int armnet_gather_scale_f32(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
+                            const float* table, int64_t nfeat, float* out, int32_t* id_status,
+                            void* stream);
+
+/* armnet_1h.py:81 alone: vals <- clamp(vals, 1e-3, 1) in place. */
+int armnet_clamp_vals_f32(float* vals, int64_t n, void* stream);
+
+/*
+ * utils/entmax.py:134 entmax_bisect(X, alpha, dim=-1, n_iter, ensure_sum_one) over the last
+ * dimension of a [rows, d] matrix (alpha == 1 -> softmax).  Same solver selection as the fused call.
+ */
+int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_sum_one, uint32_t flags,
+                      const float* X, float* P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARMNET_HIP_H */

@@ -1,0 +1,150 @@
+"""GPU parity tests proper: every call goes through the C ABI (libarmnet_hip.so) on cuda:0 and is
+compared with (i) the golden vectors captured from the real reference and (ii) the CPU oracle on
+the same inputs.  Tolerance is the one BASELINE.json's north_star states: 1e-5 fp32."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load, load_entmax, model_cases
+from model_util import build_model
+from oracle import armnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EVAL_CASES = [n for n in model_cases() if "train" not in n]
+TOL = 1e-5
+
+
+def _rel_err(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - ref))) / max(1.0, float(np.max(np.abs(ref))))
+
+
+def _run(name, flags=0, id_dtype=torch.int64):
+    from armnet_hip import native  # noqa: F401
+    meta, sd, ids, vals, ref = load(name)
+    m = build_model(meta, sd, DEV)
+    m.kernel_flags = flags
+    x = {"id": torch.from_numpy(ids).to(DEV).to(id_dtype), "value": torch.from_numpy(vals.copy()).to(DEV),
+         "y": torch.zeros(ids.shape[0])}
+    with torch.no_grad():
+        x_arm = m.arm_block(x["id"], x["value"].clone())
+        y = m(x)
+    return meta, ref, x, x_arm, y
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
+def test_model_forward_matches_reference(name):
+    meta, ref, x, x_arm, y = _run(name)
+    assert tuple(y.shape) == ref["logits"].shape                      # 0-dim when B == 1 (armnet_1h.py:98)
+    assert _rel_err(x_arm.cpu().numpy().reshape(ref["x_arm"].shape), ref["x_arm"]) <= TOL
+    assert _rel_err(y.cpu().numpy(), ref["logits"]) <= TOL
+    np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])   # in-place clamp
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
+def test_generic_kernel_matches_reference(name):
+    from armnet_hip import native
+    meta, ref, x, x_arm, y = _run(name, flags=native.F_FORCE_GENERIC)
+    assert _rel_err(x_arm.cpu().numpy().reshape(ref["x_arm"].shape), ref["x_arm"]) <= TOL
+    assert _rel_err(y.cpu().numpy(), ref["logits"]) <= TOL
+
+
+@pytest.mark.parametrize("name", [n for n in EVAL_CASES if "a1.0" not in n])
+def test_faithful_bisection_matches_reference(name):
+    from armnet_hip import native
+    meta, ref, x, x_arm, y = _run(name, flags=native.F_FAITHFUL_BISECT)
+    assert _rel_err(x_arm.cpu().numpy().reshape(ref["x_arm"].shape), ref["x_arm"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g2_criteo_1h_a2.0_stress", "g3_criteo_mh4_a1.7_stress"])
+def test_int32_ids(name):
+    meta, ref, x, x_arm, y = _run(name, id_dtype=torch.int32)
+    assert _rel_err(y.cpu().numpy(), ref["logits"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g2_criteo_1h_a1.7_stress", "g7_odd_mh3_f7_e8_h5_a2.0"])
+def test_against_oracle_on_fresh_random_inputs(name):
+    """HIP path vs the CPU oracle on inputs the fixtures do not hold (bigger batch, ragged tail)."""
+    meta, sd, ids, vals, _ = load(name)
+    c = meta["ctor"]
+    g = torch.Generator().manual_seed(123)
+    B = 1000 + 37
+    ids = torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g)
+    vals = torch.rand(B, c["nfield"], generator=g) * 1.2 - 0.1
+    m = build_model(meta, sd, DEV)
+    with torch.no_grad():
+        got = m.arm_block(ids.to(DEV), vals.clone().to(DEV)).cpu().numpy()
+    v = vals.numpy().copy()
+    want = orc.arm_block(meta["variant"], ids.numpy(), v, sd, float(c["alpha"]))
+    assert _rel_err(got, want) <= TOL
+
+
+def test_out_of_range_id_raises_indexerror():
+    meta, sd, ids, vals, _ = load("g2_criteo_1h_a2.0_stress")
+    m = build_model(meta, sd, DEV)
+    bad = ids.copy()
+    bad[3, 7] = meta["ctor"]["nfeat"]
+    with pytest.raises(IndexError):
+        m({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
+    bad[3, 7] = -1
+    with pytest.raises(IndexError):
+        m({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
+
+
+def test_forward_accepts_ids_vals_pair_and_noncontiguous_values():
+    meta, sd, ids, vals, ref = load("g2_criteo_1h_a1.5_stress")
+    m = build_model(meta, sd, DEV)
+    vt = torch.from_numpy(vals.copy()).to(DEV).t().contiguous().t()     # non-contiguous view
+    assert not vt.is_contiguous()
+    with torch.no_grad():
+        y = m(torch.from_numpy(ids).to(DEV), vt)
+    assert _rel_err(y.cpu().numpy(), ref["logits"]) <= TOL
+    np.testing.assert_array_equal(vt.cpu().numpy(), ref["vals_clamped"])
+
+
+def test_embedding_layer_matches_reference():
+    from models.layers import Embedding
+    meta, sd, ids, vals, ref = load("g2_criteo_1h_a1.7_stress")
+    emb = Embedding(meta["ctor"]["nfeat"], meta["ctor"]["nemb"])
+    emb.load_state_dict({"embedding.weight": torch.from_numpy(sd["embedding.embedding.weight"])})
+    emb = emb.to(DEV)
+    out = emb({"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(ref["vals_clamped"]).to(DEV)})
+    np.testing.assert_array_equal(out.cpu().numpy(), ref["x_emb"])     # gather * value: bit exact
+
+
+def test_entmax_matches_reference_vectors():
+    from utils.entmax import EntmaxBisect, entmax_bisect
+    for m, X, P in load_entmax():
+        got = entmax_bisect(torch.from_numpy(X).to(DEV), alpha=m["alpha"], dim=-1, n_iter=m["n_iter"],
+                            ensure_sum_one=m.get("ensure_sum_one", True)).cpu().numpy()
+        bar = 2e-6 if m["alpha"] <= 2.0 else 2e-5
+        assert float(np.max(np.abs(got - P))) <= bar, m
+    X = torch.randn(7, 5, 39, generator=torch.Generator().manual_seed(1))
+    want = orc.entmax_bisect(X.permute(0, 2, 1).numpy(), 1.7)          # dim=1 handled by movedim
+    got = EntmaxBisect(1.7, dim=1)(X.to(DEV)).permute(0, 2, 1).cpu().numpy()
+    assert float(np.max(np.abs(got - want))) <= 2e-6
+
+
+def test_entmax_edge_rows_on_device():
+    from utils.entmax import entmax_bisect
+    one_hot = entmax_bisect(torch.tensor([[5.0, 0.0, -1.0, 0.5]], device=DEV), 1.5).cpu().numpy()
+    np.testing.assert_array_equal(one_hot, [[1, 0, 0, 0]])
+    uni = entmax_bisect(torch.zeros(1, 8, device=DEV), 1.7).cpu().numpy()
+    np.testing.assert_allclose(uni, np.full((1, 8), 0.125, np.float32), rtol=3e-7)
+    nan = entmax_bisect(torch.tensor([[float("inf"), 0.0, 1.0]], device=DEV), 1.5).cpu().numpy()
+    assert np.isnan(nan).all()
+    masked = entmax_bisect(torch.tensor([[float("-inf"), 0.0, 1.0]], device=DEV), 2.0).cpu().numpy()
+    np.testing.assert_allclose(masked, [[0.0, 0.0, 1.0]], atol=1e-7)
+    sm = entmax_bisect(torch.tensor([[0.0, 1.0, 2.0]], device=DEV), 1.0).cpu().numpy()
+    np.testing.assert_allclose(sm, torch.softmax(torch.tensor([[0.0, 1.0, 2.0]]), -1).numpy(), rtol=1e-6)
+
+
+def test_attention_submodule_surface():
+    """SparseAttention / SparseAttLayer called on their own return the reference's arm_weight."""
+    for name in ("g2_criteo_1h_a1.7_stress", "g3_criteo_mh4_a2.0_stress"):
+        meta, sd, ids, vals, ref = load(name)
+        m = build_model(meta, sd, DEV)
+        with torch.no_grad():
+            w = m.attn_layer(torch.from_numpy(ref["x_emb"]).to(DEV))
+        assert _rel_err(w.cpu().numpy(), ref["arm_weight"]) <= TOL

@@ -1,0 +1,88 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/armnet_hip.h,
+argument validation works without touching a device, and the nn.Module surface mirrors the
+reference's (constructor order, state_dict keys, seeded initial weights)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load, model_cases
+from model_util import build_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from armnet_hip import native
+    lib = native.load()
+    hdr = open(os.path.join(ROOT, "include", "armnet_hip.h")).read()
+    declared = set(re.findall(r"\b(armnet_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"armnet_status", "armnet_id_type", "armnet_variant"}
+    assert declared, "header parse failed"
+    for name in declared:
+        assert hasattr(lib, name), f"libarmnet_hip.so lacks {name}"
+    assert set(native.EXPORTS) == declared
+    assert lib.armnet_abi_version() == native.ABI_VERSION
+
+
+def test_abi_argument_validation_without_device():
+    from armnet_hip import native
+    lib = native.load()
+    assert lib.armnet_clamp_vals_f32(None, ctypes.c_int64(-1), None) == native.ERR_BAD_ARG
+    assert lib.armnet_entmax_f32(ctypes.c_int64(4), 0, ctypes.c_float(1.5), 50, 1, 0, None, None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_fold_params_f32(0, 2, 4, 4, 4, *([None] * 9), ctypes.c_float(1e-5), None) == native.ERR_BAD_ARG
+    assert b"out of range" in lib.armnet_strerror(native.ERR_ID_RANGE)
+    with pytest.raises(IndexError):
+        native.check(native.ERR_ID_RANGE)
+    with pytest.raises(native.ArmnetNativeError):
+        native.check(native.ERR_UNSUPPORTED)
+
+
+@pytest.mark.parametrize("name", [n for n in model_cases() if n.endswith("fresh")])
+def test_same_seed_gives_reference_initial_weights(name):
+    """Constructor order and initialisers match the reference (armnet_1h.py:59-74, armnet.py:63-75)."""
+    meta, sd, *_ = load(name)
+    torch.manual_seed(meta["seed"])
+    m = build_model(meta)
+    msd = m.state_dict()
+    assert list(msd.keys()) == list(sd.keys())
+    for k in sd:
+        np.testing.assert_array_equal(msd[k].numpy(), sd[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", model_cases())
+def test_state_dict_round_trip(name):
+    meta, sd, *_ = load(name)
+    m = build_model(meta, sd)
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), sd[k])
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    """No CPU fallback: the product path refuses host tensors instead of computing elsewhere."""
+    from armnet_hip import native
+    meta, sd, ids, vals, _ = load("g7_odd_1h_f13_e12_h7_a1.5")
+    m = build_model(meta, sd)
+    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
+        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
+    from utils.entmax import entmax_bisect
+    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
+        entmax_bisect(torch.zeros(2, 5))
+
+
+def test_training_mode_is_refused_explicitly():
+    meta, sd, ids, vals, _ = load("g7_odd_1h_f13_e12_h7_a1.5")
+    m = build_model(meta, sd).train()
+    with pytest.raises(NotImplementedError):
+        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from armnet_hip import native
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
+        native.load()
