@@ -51,7 +51,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int E, int NQ, int NTC, int MODE, bool FROM_ROWS>
+template <int E, int NQ, int NTC, int MODE, int SRC>   // SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows
 __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(FusedArgs a) {
     constexpr int SPW = 4 / cgcd(NQ, 4);      // samples per wave-group
     constexpr int NTILE = SPW * NQ / 4;       // 16-row MFMA tiles per group
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
     constexpr int NI = NTILE * 16 / RPI;      // staging instructions per group
     constexpr int EB = E / 16;                // 16-wide blocks of the embedding dim
     constexpr int NR = SPW * NTC;             // (sample, neuron) rows per lane
+    constexpr bool FROM_ROWS = (SRC == 2);
     static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0, "shape");
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -89,8 +90,11 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
         sf_off[n] = (f < F) ? s * F + f : -1;
     }
     const bool pad_last = (4 * (NQ - 1) + g) >= F;   // this lane's last quarter-step is a pad field
-    const bool is_i64 = a.id_type == ARMNET_ID_I64;
     const bool write_vals = (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) != 0;
+    // ablation switches for profiling (tools/kbench.py); never set by the product path
+    const bool dbg_no_solve = (a.flags & 0x100u) != 0;   // skip the Newton iterations
+    const bool dbg_hot_rows = (a.flags & 0x200u) != 0;   // fold ids into 1024 rows (cache-resident gather)
+    const bool dbg_no_store = (a.flags & 0x400u) != 0;   // skip the output stores
 
     // ---- per-lane parameters of the neuron chunk (hoisted when O == 16*NTC) ---------------------
     const int n_chunks = O / (16 * NTC);
@@ -115,53 +119,64 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
     };
     if (n_chunks == 1) load_chunk_params(0);
 
-    // ---- software pipeline registers ---------------------------------------------------------------
+    // ---- software pipeline -------------------------------------------------------------------------
+    // iteration k:  stage rows(k) -> LDS | finish ids/vals(k+1) (clamp, range check) | issue row loads(k+1)
+    //               | issue RAW id/val loads(k+2) | compute(k).  Nothing loaded in an iteration is looked
+    //               at before the next one, so both legs of the id -> row latency chain overlap compute.
     f32x4 rows_cur[NI];            // raw rows of the CURRENT group (loads issued one iteration ago)
     float val_cur[NI];             // clamped values of the current group
-    uint32_t id_nxt[NI];           // validated ids of the NEXT group
-    float val_nxt[NI];
+    uint32_t raw_lo[NI], raw_hi[NI];   // untouched id words of the NEXT group (hi only for int64 ids)
+    float raw_val[NI];                 // untouched values of the next group
+    const int Bi = (int)a.B;       // launcher guarantees B < 2^31
 
-    auto fetch_ids = [&](int64_t gidx, uint32_t* ids_out, float* vals_out) {
+    auto lane_valid = [&](int n, int64_t gidx) -> bool {
+        const int64_t b0 = gidx * SPW;
+        return sf_off[n] >= 0 && gidx < ngroups && (int)b0 + s_of[n] < Bi;
+    };
+    auto fetch_raw = [&](int64_t gidx) {
         const int64_t b0 = gidx * SPW;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            const bool valid = sf_off[n] >= 0 && (b0 + s_of[n]) < a.B && gidx < ngroups;
-            const int64_t gi = valid ? b0 * F + sf_off[n] : 0;
-            uint32_t id = 0;
-            float v = 0.f;
-            if (valid) {
-                const float vraw = a.vals[gi];
-                v = clamp_val(vraw);
-                if (write_vals && chunk == 0 && v != vraw) a.vals[gi] = v;
-                if constexpr (!FROM_ROWS) {
-                    bool bad;
-                    if (is_i64) id = load_id_checked(reinterpret_cast<const int64_t*>(a.ids) + gi, a.nfeat, bad);
-                    else id = load_id_checked(reinterpret_cast<const int32_t*>(a.ids) + gi, a.nfeat, bad);
-                    if (bad && a.id_status && chunk == 0) atomicOr(a.id_status, 1);
-                }
+            const int64_t gi = lane_valid(n, gidx) ? b0 * F + sf_off[n] : 0;   // element 0 is always readable
+            raw_val[n] = a.vals[gi];
+            if constexpr (SRC == 0) {
+                const uint2 w = reinterpret_cast<const uint2*>(a.ids)[gi];
+                raw_lo[n] = w.x;
+                raw_hi[n] = w.y;
+            } else if constexpr (SRC == 1) {
+                raw_lo[n] = reinterpret_cast<const uint32_t*>(a.ids)[gi];
+                raw_hi[n] = 0u;
             }
-            ids_out[n] = id;
-            vals_out[n] = valid ? v : 0.f;      // pad rows / tail samples stage zeros
         }
     };
-    auto issue_rows = [&](int64_t gidx, const uint32_t* ids_in, f32x4* rows_out) {
+    // clamp (armnet_1h.py:81), optional write-back of the clamp, id range check; then the row loads
+    auto finish_and_issue = [&](int64_t gidx, float* vals_out) {
         const int64_t b0 = gidx * SPW;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
+            const bool valid = lane_valid(n, gidx);
+            const float vraw = raw_val[n];
+            const float v = clamp_val(vraw);
+            if (write_vals && valid && chunk == 0 && v != vraw) a.vals[b0 * F + sf_off[n]] = v;
+            vals_out[n] = valid ? v : 0.f;       // pad rows / tail samples stage zeros
             const float* src;
             if constexpr (FROM_ROWS) {
-                const bool valid = sf_off[n] >= 0 && (b0 + s_of[n]) < a.B && gidx < ngroups;
                 src = a.rows + (valid ? (b0 * F + sf_off[n]) * (int64_t)E : 0) + chunk * 4;
             } else {
-                src = a.table + (size_t)ids_in[n] * E + chunk * 4;
+                uint32_t id = raw_lo[n];
+                const bool bad = valid && (raw_hi[n] != 0u || id >= (uint32_t)a.nfeat);
+                if (bad && a.id_status && chunk == 0) atomicOr(a.id_status, 1);
+                if (bad || !valid) id = 0u;
+                if (dbg_hot_rows) id &= 1023u;
+                src = a.table + (size_t)id * E + chunk * 4;
             }
-            rows_out[n] = *reinterpret_cast<const f32x4*>(src);
+            rows_cur[n] = *reinterpret_cast<const f32x4*>(src);
         }
     };
 
-    fetch_ids(grp, id_nxt, val_cur);
-    issue_rows(grp, id_nxt, rows_cur);
-    fetch_ids(grp + nwaves, id_nxt, val_nxt);
+    fetch_raw(grp);
+    finish_and_issue(grp, val_cur);
+    fetch_raw(grp + nwaves);
 
     for (; grp < ngroups; grp += nwaves) {
         const int64_t b0 = grp * SPW;
@@ -173,11 +188,9 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
             const int row = n * RPI + lane / CH;
             *reinterpret_cast<f32x4*>(xt + row * ES + chunk * 4) = r;
         }
-        // ---- keep the memory pipeline full: rows of the next group, ids of the one after --------
-        issue_rows(grp + nwaves, id_nxt, rows_cur);
-#pragma unroll
-        for (int n = 0; n < NI; ++n) val_cur[n] = val_nxt[n];
-        fetch_ids(grp + 2 * nwaves, id_nxt, val_nxt);
+        // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
+        finish_and_issue(grp + nwaves, val_cur);
+        fetch_raw(grp + 2 * nwaves);
         wave_lds_fence();
 
         for (int ch = 0; ch < n_chunks; ++ch) {
@@ -257,7 +270,7 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
                         tau[s * NTC + nt] = t0;
                     }
                 // Newton from the left; wave-uniform loop, rows drop out as they converge
-                for (int it = 0; it < kNewtonMaxIter; ++it) {
+                for (int it = 0; it < (dbg_no_solve ? 0 : kNewtonMaxIter); ++it) {
                     bool any_active = false;
 #pragma unroll
                     for (int s = 0; s < SPW; ++s)
@@ -343,7 +356,7 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
                             c2[nt][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, nt, j), c2[nt][eb], 0, 0, 0);
                     }
                 }
-                if (b0 + s < a.B) {
+                if (b0 + s < a.B && !dbg_no_store) {
 #pragma unroll
                     for (int nt = 0; nt < NTC; ++nt) {
                         float* dst = a.out + ((b0 + s) * O + o0 + 16 * nt + c) * (int64_t)E + 4 * g;
@@ -374,7 +387,7 @@ bool fused_mfma_supports(int F, int E, int O) {
     return false;
 }
 
-template <int E, int NQ, int MODE, bool FROM_ROWS>
+template <int E, int NQ, int MODE, int SRC>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
     constexpr int NTC = 2;
     constexpr int SPW = 4 / cgcd(NQ, 4);
@@ -385,7 +398,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     const int64_t resident = 256 * (lds > 40 * 1024 ? 1 : 2);    // blocks the chip holds at once
     // persistent grid-stride waves: the software pipeline's prologue is paid once per wave
     const int64_t want = blocks < resident ? blocks : resident;
-    auto kern = fused_mfma_kernel<E, NQ, NTC, MODE, FROM_ROWS>;
+    auto kern = fused_mfma_kernel<E, NQ, NTC, MODE, SRC>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -394,26 +407,28 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     return ARMNET_OK;
 }
 
-template <int E, int NQ, bool FROM_ROWS>
+template <int E, int NQ, int SRC>
 static int launch_mode(const FusedArgs& a, hipStream_t st) {
     switch (a.cfg.mode) {
-        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, FROM_ROWS>(a, st);
-        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, FROM_ROWS>(a, st);
-        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, FROM_ROWS>(a, st);
-        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, FROM_ROWS>(a, st);
+        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC>(a, st);
+        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);
+        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);
+        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);
         default: return ARMNET_ERR_UNSUPPORTED;
     }
 }
 
 int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
+    if (a.B >= ((int64_t)1 << 31) / a.F) return ARMNET_ERR_UNSUPPORTED;   // 32-bit sample*field indices
     if (!fused_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (((uintptr_t)a.out | (uintptr_t)a.q_fold | (uintptr_t)(a.rows ? a.rows : a.table)) % 16) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (a.F + 3) / 4;
-    const bool fr = a.rows != nullptr;
-#define DISPATCH(E_, NQ_)                                                     \
-    if (a.E == E_ && nq == NQ_)                                               \
-        return fr ? launch_mode<E_, NQ_, true>(a, st) : launch_mode<E_, NQ_, false>(a, st);
+    const int src = a.rows != nullptr ? 2 : (a.id_type == ARMNET_ID_I64 ? 0 : 1);
+#define DISPATCH(E_, NQ_)                                                                        \
+    if (a.E == E_ && nq == NQ_)                                                                  \
+        return src == 2 ? launch_mode<E_, NQ_, 2>(a, st)                                         \
+                        : (src == 0 ? launch_mode<E_, NQ_, 0>(a, st) : launch_mode<E_, NQ_, 1>(a, st));
     DISPATCH(16, 10)
     DISPATCH(64, 10)
     DISPATCH(32, 6)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for the fused kernel on the GPU box (run through gpurun):
+#   pass 0: kernel trace + stats (timings)          pass 1..n: PMC counters, one group per process
+# usage: tools/profile.sh <outdir-under-gpurun_out> -- <command...>
+set -u
+OUT=$1; shift; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$ROOT/gpurun_out/$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() { # name, extra args...
+  local name=$1; shift
+  rocprofv3 "$@" --kernel-trace --output-format csv -d "$ROOT/gpurun_out/$OUT/$name" -- "${CMD[@]}" > "$ROOT/gpurun_out/$OUT/$name.log" 2>&1
+}
+CMD=("$@")
+run trace --stats
+run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+run pmc_sq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_WAIT_INST_LDS
+run pmc_sq3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE
+run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT
+find "$ROOT/gpurun_out/$OUT" -name "*.csv" | head -40
