@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_PKG, "lib", "libarmnet_hip.so")
+LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 ABI_VERSION = 1
 

@@ -1,47 +1,56 @@
 // fused_mfma.hip — the fused ARM block on the CDNA4 matrix cores (gfx950), fp32 end to end.
 //
+// Measured facts this kernel is built around (tools/ubench/valu_rate.hip, profiles/):
+//   * v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and its cycles ADD to the VALU cycles of
+//     the same SIMD (no overlap) -> the budget per sample is 40 MFMAs * 32 cycles + every VALU op;
+//   * one wave issues a VALU op at most every ~8 cycles -> >= 4 waves/SIMD (<= 128 VGPRs) are needed;
+//   * the LDS pipe is otherwise idle -> cross-lane reductions and parameter fetches go through LDS.
+//
 // One WAVE owns a group of SPW samples at a time and never talks to another wave (wave-private
-// LDS tile, no block barrier).  Per group:
+// LDS tile, no block barrier after the prologue).  Per group:
 //
 //   stage     coalesced 16-B chunk loads of the F embedding rows of each sample (adjacent lanes
-//             share a row), scaled by clamp(value), written to the wave's LDS tile.  Rows for the
-//             NEXT group are already in flight (registers) and ids/values for the group after that
-//             are being fetched, so the id -> row dependent latency chain is off the critical path.
-//   MFMA #1   gates  G[(s,f), o] = X[(s,f), :] . q_fold[o, :]   v_mfma_f32_16x16x4_f32, exact fp32.
-//             The tile rows are ordered so that accumulator register r of tile t is "quarter-step"
-//             q = 4t + r = s*NQ + j of ONE sample: lane (c = l&15, g = l>>4) then holds, for neuron
-//             o = 16*nt + c, the gates of fields f = 4j + g, j = 0..NQ-1  -> NQ values per row.
-//   sparse    entmax / softmax over the F fields of every (sample, neuron) row, in registers.  A row
-//   map       is spread over the 4 lane groups g: reductions are 2 v_permlane{32,16}_swap + 2 adds.
+//             share a row), scaled by clamp(value), written to the wave's LDS tile.  Rows of the
+//             NEXT group are already in flight (registers) and the raw ids/values of the group after
+//             that are being fetched: both legs of the id -> row latency chain overlap compute.
+//   per 16-neuron pass nt:
+//   MFMA #1   gates  G[(s,f), o] = X[(s,f), :] . q_fold[o, :]   (v_mfma_f32_16x16x4_f32, exact fp32).
+//             Tile rows are ordered so that accumulator register r of tile t is "quarter-step"
+//             q = 4t + r = s*NQ + j of ONE sample: lane (c = l&15, g = l>>4) holds, for neuron
+//             o = 16*nt + c, the gates of fields f = 4j + g, j = 0..NQ-1.
+//   sparse    entmax / softmax over the fields of each (sample, neuron) row, in registers, two
+//   map       elements per instruction: t = clamp01(x - tau) is ONE v_pk_add_f32 with the neg and
+//             clamp modifiers (x - tau <= 1 always holds because tau >= max - 1).  A row is spread
+//             over the 4 lane groups g: partial sums meet through a 512-B LDS scratch.
 //             alpha = 2: Michelot (= Newton from the left, finite), alpha = 1.5 / generic: Newton.
 //   MFMA #2   Z^T[e, o] = sum_f X[f, e] * W[o, f]:  the C layout of MFMA #1 IS the B-operand layout
-//             of MFMA #2 (k = lane group g <-> field 4j+g), so the weights never move; the
-//             contraction index is just visited in the permuted order both operands agree on.
-//   epilogue  exp, eval-BatchNorm affine, one 16-byte store per lane (lane holds 4 consecutive e).
+//             of MFMA #2 (k = lane group g <-> field 4j+g): the weights never move.
+//   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte
+//             store per lane (a lane holds 4 consecutive e of one neuron row).
 //
-// LDS tile: NTILE*16 rows x (E+4) floats (row stride padded by one 16-B slot: conflict-free
-// ds_read_b32 column reads for MFMA #2, <= 2-way on the ds_read_b128 row reads of MFMA #1).
+// LDS: per wave  NTILE*16 rows x (E+4) floats (padded stride: conflict-free column reads) + 1 KiB
+// reduction scratch; per block the folded parameters in lane-ready order (q_fold fragments, values
+// pairs, BN affine), staged once.
 #include "armnet_common.h"
 
 namespace armnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 
-__device__ __forceinline__ float sum_over_groups(float v) {
-    // all-reduce over the 4 lane groups {l, l^16, l^32, l^48}: two swaps + two adds
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+// t = clamp01(x - tau), two elements per instruction
+__device__ __forceinline__ f32x2 pk_sub_clamp01(f32x2 x, f32x2 tau) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "v"(tau));
+    return r;
 }
-
-__device__ __forceinline__ float max_over_groups(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+// clamp01(a * b), two elements per instruction (indicator of a > 0 when b is huge)
+__device__ __forceinline__ f32x2 pk_mul_clamp01(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -51,34 +60,95 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int E, int NQ, int NTC, int MODE, int SRC>   // SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows
-__global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(FusedArgs a) {
-    constexpr int SPW = 4 / cgcd(NQ, 4);      // samples per wave-group
-    constexpr int NTILE = SPW * NQ / 4;       // 16-row MFMA tiles per group
+// All-reduce of two per-lane partials over the 4 lane groups {l, l^16, l^32, l^48} through LDS:
+// lane-linear 8-byte writes (conflict-free), then every lane reads the 4 partials of its column.
+struct Red2 { f32x2 g0, g1, g2, g3; };
+__device__ __forceinline__ void red_write(float* scratch, int slot, int lane, float a, float b) {
+    *reinterpret_cast<f32x2*>(scratch + slot * 128 + lane * 2) = f32x2{a, b};
+}
+__device__ __forceinline__ Red2 red_read(const float* scratch, int slot, int c) {
+    const float* p = scratch + slot * 128 + c * 2;
+    Red2 r;
+    r.g0 = *reinterpret_cast<const f32x2*>(p);
+    r.g1 = *reinterpret_cast<const f32x2*>(p + 32);
+    r.g2 = *reinterpret_cast<const f32x2*>(p + 64);
+    r.g3 = *reinterpret_cast<const f32x2*>(p + 96);
+    return r;
+}
+
+// max without the sNaN-quieting v_max x,x,x the compiler adds around fmaxf on MFMA results
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// SPW samples per wave-group (SPW*NQ quarter-steps, padded up to whole 16-row tiles);
+// SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows; WPS = waves/SIMD the register budget targets
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS>
+__global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
+    constexpr int NQT = SPW * NQ;             // real quarter-steps per group
+    constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group
     constexpr int ES = E + 4;                 // LDS row stride (floats)
     constexpr int CH = E / 4;                 // 16-byte chunks per row
     constexpr int RPI = 64 / CH;              // rows per staging instruction
     constexpr int NI = NTILE * 16 / RPI;      // staging instructions per group
     constexpr int EB = E / 16;                // 16-wide blocks of the embedding dim
-    constexpr int NR = SPW * NTC;             // (sample, neuron) rows per lane
+    constexpr int NP = NQ / 2;                // element pairs per row
     constexpr bool FROM_ROWS = (SRC == 2);
-    static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0, "shape");
+    constexpr int TILE_FLOATS = NTILE * 16 * ES;
+    constexpr int WAVE_FLOATS = TILE_FLOATS + 256;       // + reduction scratch (2 slots x 128 floats)
+    static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0 && NQ % 2 == 0 && SPW <= 2, "shape");
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float* xt = lds_all + wave * (NTILE * 16 * ES);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
     const int c = lane & 15, g = lane >> 4;
     const int F = a.F, O = a.O;
-    const int64_t ngroups = (a.B + SPW - 1) / SPW;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    const int NT = O / 16;                    // 16-neuron passes
+    float* xt = lds_all + wave * WAVE_FLOATS;
+    float* red = xt + TILE_FLOATS;
+    // block-shared, lane-ready parameters
+    float* p_bq = lds_all + 4 * WAVE_FLOATS;               // [NT][EB][64] f32x4
+    float* p_vv = p_bq + NT * EB * 64 * 4;                 // [NT][NP][64] f32x2
+    float* p_bn = p_vv + NT * NP * 64 * 2;                 // [NT][16] f32x2 {scale, shift}
+
+    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+        const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
+        const int o = 16 * nt + (l & 15);
+        *reinterpret_cast<f32x4*>(p_bq + i * 4) =
+            *reinterpret_cast<const f32x4*>(a.q_fold + (size_t)o * E + 16 * kb + 4 * (l >> 4));
+    }
+    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
+        const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
+        const int o = 16 * nt + (l & 15);
+        const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
+        f32x2 v;
+        v[0] = f0 < F ? a.values[(size_t)o * F + f0] : 0.f;
+        v[1] = f1 < F ? a.values[(size_t)o * F + f1] : 0.f;
+        *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
+    }
+    for (int i = threadIdx.x; i < NT * 16; i += 256)
+        *reinterpret_cast<f32x2*>(p_bn + i * 2) = f32x2{a.bn_scale[i], a.bn_shift[i]};
+    __syncthreads();
+
+    // all group bookkeeping is 32-bit and wave-uniform (SALU): launcher guarantees B*F*8 < 2^32
+    const int Bi = (int)a.B;
+    const uint32_t BF = (uint32_t)Bi * (uint32_t)F;
+    const int ngroups = (Bi + SPW - 1) / SPW;
+    const int nwaves = (int)gridDim.x * 4;
+    int grp = (int)blockIdx.x * 4 + wave;
     if (grp >= ngroups) return;
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
-    int sf_off[NI];      // s*F + f of the row this lane stages in instruction n, or -1 for a pad row
-    int s_of[NI];
+    uint32_t sfo[NI];    // s*F + f of the row this lane stages in instruction n (0 for a pad row)
+    bool pad[NI];        // pad row: stages zeros
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         const int row = n * RPI + lane / CH;
@@ -86,291 +156,314 @@ __global__ void __launch_bounds__(256, (E >= 64 ? 1 : 2)) fused_mfma_kernel(Fuse
         const int q = 4 * t + (i & 3);
         const int s = q / NQ, j = q - s * NQ;
         const int f = 4 * j + (i >> 2);
-        s_of[n] = s;
-        sf_off[n] = (f < F) ? s * F + f : -1;
+        pad[n] = !(q < NQT && f < F);
+        sfo[n] = pad[n] ? 0u : (uint32_t)(s * F + f);
     }
-    const bool pad_last = (4 * (NQ - 1) + g) >= F;   // this lane's last quarter-step is a pad field
+    const float padneg = ((4 * (NQ - 1) + g) >= F) ? -INFINITY : 0.f;   // added to this lane's last gate
     const bool write_vals = (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) != 0;
+    const bool check_ids = a.id_status != nullptr;
     // ablation switches for profiling (tools/kbench.py); never set by the product path
     const bool dbg_no_solve = (a.flags & 0x100u) != 0;   // skip the Newton iterations
     const bool dbg_hot_rows = (a.flags & 0x200u) != 0;   // fold ids into 1024 rows (cache-resident gather)
     const bool dbg_no_store = (a.flags & 0x400u) != 0;   // skip the output stores
-
-    // ---- per-lane parameters of the neuron chunk (hoisted when O == 16*NTC) ---------------------
-    const int n_chunks = O / (16 * NTC);
-    f32x4 bq[NTC][EB];     // q_fold[o][16kb + 4g .. +3]          (B operand of MFMA #1)
-    float vv[NTC][NQ];     // values[o][4j + g]
-    float sc[NTC], sh[NTC];
-    auto load_chunk_params = [&](int o0) {
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {
-            const int o = o0 + 16 * nt + c;
-#pragma unroll
-            for (int kb = 0; kb < EB; ++kb)
-                bq[nt][kb] = *reinterpret_cast<const f32x4*>(a.q_fold + (size_t)o * E + 16 * kb + 4 * g);
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const int f = 4 * j + g;
-                vv[nt][j] = (f < F) ? a.values[(size_t)o * F + f] : 0.f;
-            }
-            sc[nt] = a.bn_scale[o];
-            sh[nt] = a.bn_shift[o];
-        }
-    };
-    if (n_chunks == 1) load_chunk_params(0);
+    const uint32_t id_mask = dbg_hot_rows ? 1023u : 0xffffffffu;
+    const uint32_t id_max = (uint32_t)a.nfeat - 1u;
+    const char* row_base = reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) + chunk * 16;
 
     // ---- software pipeline -------------------------------------------------------------------------
-    // iteration k:  stage rows(k) -> LDS | finish ids/vals(k+1) (clamp, range check) | issue row loads(k+1)
-    //               | issue RAW id/val loads(k+2) | compute(k).  Nothing loaded in an iteration is looked
-    //               at before the next one, so both legs of the id -> row latency chain overlap compute.
-    f32x4 rows_cur[NI];            // raw rows of the CURRENT group (loads issued one iteration ago)
-    float val_cur[NI];             // clamped values of the current group
-    uint32_t raw_lo[NI], raw_hi[NI];   // untouched id words of the NEXT group (hi only for int64 ids)
-    float raw_val[NI];                 // untouched values of the next group
-    const int Bi = (int)a.B;       // launcher guarantees B < 2^31
+    // iteration k:  stage rows(k) -> LDS | range-check ids(k+1), issue row + value loads(k+1)
+    //               | issue RAW id loads(k+2) | compute(k).  Nothing loaded in an iteration is looked at
+    //               before the next one.  Groups past the end re-read the last group (results unused).
+    f32x4 rows_cur[NI];
+    float val_cur[NI];
+    uint32_t raw_lo[NI], raw_hi[NI];
 
-    auto lane_valid = [&](int n, int64_t gidx) -> bool {
-        const int64_t b0 = gidx * SPW;
-        return sf_off[n] >= 0 && gidx < ngroups && (int)b0 + s_of[n] < Bi;
+    auto elem_index = [&](int gidx, int n) -> uint32_t {
+        // element (sample, field) index, clamped into the arrays: a short last group re-reads valid memory
+        const int gc = gidx < ngroups ? gidx : ngroups - 1;
+        const uint32_t idx = (uint32_t)(gc * SPW) * (uint32_t)F + sfo[n];
+        return idx < BF ? idx : BF - 1u;
     };
-    auto fetch_raw = [&](int64_t gidx) {
-        const int64_t b0 = gidx * SPW;
+    auto fetch_raw = [&](int gidx) {
+        if constexpr (!FROM_ROWS) {
 #pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            const int64_t gi = lane_valid(n, gidx) ? b0 * F + sf_off[n] : 0;   // element 0 is always readable
-            raw_val[n] = a.vals[gi];
-            if constexpr (SRC == 0) {
-                const uint2 w = reinterpret_cast<const uint2*>(a.ids)[gi];
-                raw_lo[n] = w.x;
-                raw_hi[n] = w.y;
-            } else if constexpr (SRC == 1) {
-                raw_lo[n] = reinterpret_cast<const uint32_t*>(a.ids)[gi];
-                raw_hi[n] = 0u;
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t idx = elem_index(gidx, n);
+                if constexpr (SRC == 0) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.ids) + (size_t)(idx * 8u));
+                    raw_lo[n] = w.x;
+                    raw_hi[n] = w.y;
+                } else {
+                    raw_lo[n] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.ids) + (size_t)(idx * 4u));
+                    raw_hi[n] = 0u;
+                }
             }
         }
     };
-    // clamp (armnet_1h.py:81), optional write-back of the clamp, id range check; then the row loads
-    auto finish_and_issue = [&](int64_t gidx, float* vals_out) {
-        const int64_t b0 = gidx * SPW;
+    auto issue_rows_vals = [&](int gidx) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            const bool valid = lane_valid(n, gidx);
-            const float vraw = raw_val[n];
-            const float v = clamp_val(vraw);
-            if (write_vals && valid && chunk == 0 && v != vraw) a.vals[b0 * F + sf_off[n]] = v;
-            vals_out[n] = valid ? v : 0.f;       // pad rows / tail samples stage zeros
-            const float* src;
+            const uint32_t idx = elem_index(gidx, n);
+            val_cur[n] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.vals) + (size_t)(idx * 4u));
+            const char* src;
             if constexpr (FROM_ROWS) {
-                src = a.rows + (valid ? (b0 * F + sf_off[n]) * (int64_t)E : 0) + chunk * 4;
+                src = row_base + (size_t)idx * (size_t)(E * 4);
             } else {
                 uint32_t id = raw_lo[n];
-                const bool bad = valid && (raw_hi[n] != 0u || id >= (uint32_t)a.nfeat);
-                if (bad && a.id_status && chunk == 0) atomicOr(a.id_status, 1);
-                if (bad || !valid) id = 0u;
-                if (dbg_hot_rows) id &= 1023u;
-                src = a.table + (size_t)id * E + chunk * 4;
+                if (check_ids) {                                   // wave-uniform
+                    const bool bad = !pad[n] && (raw_hi[n] != 0u || id > id_max);
+                    if (bad && chunk == 0) atomicOr(a.id_status, 1);
+                }
+                id = (id < id_max ? id : id_max) & id_mask;       // memory-safe even when unchecked
+                src = row_base + (size_t)id * (size_t)(E * 4);
             }
             rows_cur[n] = *reinterpret_cast<const f32x4*>(src);
         }
     };
 
     fetch_raw(grp);
-    finish_and_issue(grp, val_cur);
+    issue_rows_vals(grp);
     fetch_raw(grp + nwaves);
 
+    const float am1 = a.cfg.am1;
+    const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
+    const float invF = 1.0f / (float)F;
+    const float tau_off = a.cfg.tau_hi_off;
+    const float L2E = 1.44269502162933349609375f;
+
     for (; grp < ngroups; grp += nwaves) {
-        const int64_t b0 = grp * SPW;
+        const int b0 = grp * SPW;
         // ---- stage the current group's rows (scaled) into the wave's LDS tile -----------------------
         wave_lds_fence();
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            f32x4 r = rows_cur[n] * val_cur[n];
+            // clamp (armnet_1h.py:81; NaN stays NaN), optional write-back of the clamp, scale (layers.py:21)
+            const float vraw = val_cur[n];
+            float v = __builtin_amdgcn_fmed3f(vraw, 1e-3f, 1.0f);
+            v = (vraw != vraw) ? vraw : v;
+            if (write_vals && v != vraw && chunk == 0 && !pad[n]) {
+                const uint32_t idx = (uint32_t)b0 * (uint32_t)F + sfo[n];
+                if (idx < BF) a.vals[idx] = v;
+            }
+            const f32x4 r = rows_cur[n] * (pad[n] ? 0.f : v);       // pad rows stage zeros
             const int row = n * RPI + lane / CH;
             *reinterpret_cast<f32x4*>(xt + row * ES + chunk * 4) = r;
         }
         // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
-        finish_and_issue(grp + nwaves, val_cur);
+        issue_rows_vals(grp + nwaves);
         fetch_raw(grp + 2 * nwaves);
         wave_lds_fence();
 
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int o0 = ch * 16 * NTC;
-            if (n_chunks > 1) load_chunk_params(o0);
-
-            // ---- MFMA #1: gates ---------------------------------------------------------------------
-            f32x4 c1[NTILE][NTC];
+        for (int nt = 0; nt < NT; ++nt) {
+            // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
+            f32x4 c1[NTILE];
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) {
+            for (int kb = 0; kb < EB; ++kb) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
+                f32x4 av[NTILE];
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt) c1[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NTILE; ++t)
+                    av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
 #pragma unroll
-                for (int kb = 0; kb < EB; ++kb) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int nt = 0; nt < NTC; ++nt)
-                            c1[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bq[nt][kb][kk], c1[t][nt], 0, 0, 0);
-                }
-            }
-#define XG(s, nt, j) c1[((s) * NQ + (j)) >> 2][nt][((s) * NQ + (j)) & 3]
-
-            // ---- sparse map over the fields, rows spread over the 4 lane groups ---------------------
-            float tau[NR], inv[NR];
-            if constexpr (MODE == SOLVE_SOFTMAX) {
-#pragma unroll
-                for (int s = 0; s < SPW; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            float x = XG(s, nt, j);
-                            sm += x;
-                            if (j == NQ - 1 && pad_last) x = -INFINITY;
-                            XG(s, nt, j) = x;
-                            mx = fmaxf(mx, x);
-                        }
-                        mx = max_over_groups(mx);
-                        sm = sum_over_groups(sm);
-                        float S = 0.f;
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            const float p = expf(XG(s, nt, j) - mx);
-                            XG(s, nt, j) = p;
-                            S += p;
-                        }
-                        S = sum_over_groups(S);
-                        if (sm != sm) S = NAN;
-                        inv[s * NTC + nt] = 1.0f / S;
-                    }
-            } else {
-                const float am1 = a.cfg.am1;
-                const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
-                const float invF = 1.0f / (float)F;
-                // scale (entmax.py:42), starting threshold
-#pragma unroll
-                for (int s = 0; s < SPW; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            float x = XG(s, nt, j);
-                            if constexpr (MODE != SOLVE_MICHELOT) x *= am1;
-                            sm += x;                                    // a pad field's gate is exactly 0
-                            if (j == NQ - 1 && pad_last) x = -INFINITY;
-                            XG(s, nt, j) = x;
-                            mx = fmaxf(mx, x);
-                        }
-                        mx = max_over_groups(mx);
-                        sm = sum_over_groups(sm);
-                        float t0 = fmaxf(mx - 1.0f, sm * invF - a.cfg.tau_hi_off);
-                        if (!(mx < INFINITY) || sm != sm) t0 = NAN;     // +inf / NaN gate -> NaN row
-                        tau[s * NTC + nt] = t0;
-                    }
-                // Newton from the left; wave-uniform loop, rows drop out as they converge
-                for (int it = 0; it < (dbg_no_solve ? 0 : kNewtonMaxIter); ++it) {
-                    bool any_active = false;
-#pragma unroll
-                    for (int s = 0; s < SPW; ++s)
-#pragma unroll
-                        for (int nt = 0; nt < NTC; ++nt) {
-                            const float tk = tau[s * NTC + nt];
-                            float S = 0.f, Dv = 0.f;
-#pragma unroll
-                            for (int j = 0; j < NQ; ++j) {
-                                const float t = fmaxf(XG(s, nt, j) - tk, 0.f);
-                                if constexpr (MODE == SOLVE_MICHELOT) {
-                                    S += t;
-                                    Dv += (t > 0.f) ? 1.f : 0.f;
-                                } else if constexpr (MODE == SOLVE_NEWTON15) {
-                                    S = fmaf(t, t, S);
-                                    Dv += t;
-                                } else {
-                                    const float u = t > 0.f ? pow_pos(t, rm1) : 0.f;
-                                    S = fmaf(u, t, S);
-                                    Dv += u;
-                                }
-                            }
-                            S = sum_over_groups(S);
-                            Dv = sum_over_groups(Dv);
-                            if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
-                            if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
-                            const float f = S - 1.0f;
-                            const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tk);   // Newton self-corrects: 1-ulp rcp is enough
-                            const bool act = (f > kNewtonTol) && (tn > tk);
-                            tau[s * NTC + nt] = act ? tn : tk;
-                            any_active |= act;
-                        }
-                    if (!__builtin_amdgcn_ballot_w64(any_active)) break;
-                }
-                // p at the converged threshold, row sum for the normalisation (entmax.py:63-64)
-#pragma unroll
-                for (int s = 0; s < SPW; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        const float tk = tau[s * NTC + nt];
-                        float S = 0.f;
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            const float t = fmaxf(XG(s, nt, j) - tk, 0.f);
-                            float p;
-                            if constexpr (MODE == SOLVE_MICHELOT) p = t;
-                            else if constexpr (MODE == SOLVE_NEWTON15) p = t * t;
-                            else p = t > 0.f ? pow_pos(t, rr) : 0.f;
-                            XG(s, nt, j) = p;
-                            S += p;
-                        }
-                        S = sum_over_groups(S);
-                        if (tk != tk) S = NAN;
-                        inv[s * NTC + nt] = 1.0f / S;
+                    for (int t = 0; t < NTILE; ++t) {
+                        if (kb == 0 && kk == 0)
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
-            // ---- value weighting (armnet_1h.py:34): W = p/sum * values, in place -------------------
-#pragma unroll
-            for (int s = 0; s < SPW; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NTC; ++nt)
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j)
-                        XG(s, nt, j) = (XG(s, nt, j) * inv[s * NTC + nt]) * vv[nt][j];
+            // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
+#define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]
+#define XP_GET(s, jp) (f32x2{XG(s, 2 * (jp)), XG(s, 2 * (jp) + 1)})
+#define XP_SET(s, jp, v)              \
+    do {                              \
+        const f32x2 _v = (v);         \
+        XG(s, 2 * (jp)) = _v[0];      \
+        XG(s, 2 * (jp) + 1) = _v[1];  \
+    } while (0)
+            const float* vv_base = p_vv + (nt * NP * 64 + lane) * 2;
+#define VV(jp) (*reinterpret_cast<const f32x2*>(vv_base + (jp) * 128))
 
-            // ---- MFMA #2: Z^T[e, o] = sum_f X[f, e] * W[o, f];  epilogue; store ---------------------
+            // ---- sparse map over the fields ------------------------------------------------------------
+            // On exit XG holds the UNNORMALISED weights p * values and kexp[s] = log2(e) / sum(p).
+            float kexp[SPW];
+            // row sum (for the mean start / NaN detection) and row max, partials to LDS
+            wave_lds_fence();
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
-                f32x4 c2[NTC][EB];
+                f32x2 sm2;
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt)
+                for (int jp = 0; jp < NP; ++jp) {
+                    f32x2 x = XP_GET(s, jp);
+                    if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
+                        x *= f32x2{am1, am1};               // entmax.py:42
+                        XP_SET(s, jp, x);
+                    }
+                    sm2 = jp == 0 ? x : sm2 + x;            // a pad field's gate is exactly 0
+                }
+                XG(s, NQ - 1) += padneg;                    // pad field -> -inf (never in the support)
+                float mx = vmax3(XG(s, 0), XG(s, 1), XG(s, 2));
 #pragma unroll
-                    for (int eb = 0; eb < EB; ++eb) c2[nt][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 3; j + 1 < NQ; j += 2) mx = vmax3(mx, XG(s, j), XG(s, j + 1));
+                if (NQ % 2 == 0) mx = vmax2(mx, XG(s, NQ - 1));
+                red_write(red, s & 1, lane, mx, sm2[0] + sm2[1]);
+            }
+            wave_lds_fence();
+            float tau[SPW], Ssum[SPW];
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const int q = s * NQ + j;
-                    const int row = 16 * (q >> 2) + 4 * g + (q & 3);
+            for (int s = 0; s < SPW; ++s) {
+                const Red2 r = red_read(red, s & 1, c);
+                const float mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
+                const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                if constexpr (MODE == SOLVE_SOFTMAX) {
+                    tau[s] = mx + (sm - sm);                // NaN / inf anywhere -> NaN row
+                } else {
+                    // tau0 = max(mx - 1, mean - d^-(alpha-1)) <= root; NaN/inf gates poison the row
+                    tau[s] = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
+                }
+                Ssum[s] = 1.0f;
+            }
+            if constexpr (MODE == SOLVE_SOFTMAX) {
+                wave_lds_fence();
 #pragma unroll
-                    for (int eb = 0; eb < EB; ++eb) {
-                        const float a2 = xt[row * ES + 16 * eb + c];
+                for (int s = 0; s < SPW; ++s) {
+                    float S = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < NTC; ++nt)
-                            c2[nt][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, nt, j), c2[nt][eb], 0, 0, 0);
+                    for (int j = 0; j < NQ; ++j) {
+                        const float p = __builtin_amdgcn_exp2f((XG(s, j) - tau[s]) * L2E);
+                        S += p;
+                        XG(s, j) = p * VV(j >> 1)[j & 1];
+                    }
+                    red_write(red, s & 1, lane, S, 0.f);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    const Red2 q = red_read(red, s & 1, c);
+                    Ssum[s] = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
+                }
+            } else {
+                // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
+                // they converge.  When the loop ends every row's S was evaluated at its final threshold.
+                for (int it = 0; it < kNewtonMaxIter; ++it) {
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const f32x2 tk = {tau[s], tau[s]};
+                        f32x2 S2, D2;
+#pragma unroll
+                        for (int jp = 0; jp < NP; ++jp) {
+                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                            f32x2 sv, dv;
+                            if constexpr (MODE == SOLVE_MICHELOT) {
+                                sv = t;
+                                dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
+                            } else if constexpr (MODE == SOLVE_NEWTON15) {
+                                sv = t * t;
+                                dv = t;
+                            } else {
+                                f32x2 u;   // t^(r-1); log2(0) = -inf -> exp2(-inf) = 0 (r > 1)
+                                u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
+                                u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
+                                sv = u * t;
+                                dv = u;
+                            }
+                            S2 = jp == 0 ? sv : S2 + sv;
+                            D2 = jp == 0 ? dv : D2 + dv;
+                        }
+                        red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
+                    }
+                    wave_lds_fence();
+                    bool any_active = false;
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const Red2 r = red_read(red, s & 1, c);
+                        const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);     // {S, Dv} in one register pair
+                        float Dv = sd[1];
+                        if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
+                        if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
+                        Ssum[s] = sd[0];
+                        const float f = sd[0] - 1.0f;
+                        const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
+                        const bool act = (f > kNewtonTol) && (tn > tau[s]) && !dbg_no_solve;
+                        tau[s] = act ? tn : tau[s];
+                        any_active |= act;
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(any_active)) break;
+                }
+                // unnormalised weights p * values (armnet_1h.py:34)
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    const f32x2 tk = {tau[s], tau[s]};
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                        f32x2 p;
+                        if constexpr (MODE == SOLVE_MICHELOT) p = t;
+                        else if constexpr (MODE == SOLVE_NEWTON15) p = t * t;
+                        else {
+                            p[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));
+                            p[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
+                        }
+                        XP_SET(s, jp, p * VV(jp));
                     }
                 }
-                if (b0 + s < a.B && !dbg_no_store) {
+            }
+            // normaliser (entmax.py:63-64) folded into the exponent scale: 1/S by rcp + one Newton step
 #pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        float* dst = a.out + ((b0 + s) * O + o0 + 16 * nt + c) * (int64_t)E + 4 * g;
+            for (int s = 0; s < SPW; ++s) {
+                const float S = Ssum[s] + (tau[s] - tau[s]);        // NaN threshold -> NaN row
+                float r = __builtin_amdgcn_rcpf(S);
+                r = fmaf(fmaf(-S, r, 1.0f), r, r);
+                kexp[s] = L2E * r;
+            }
+
+            // ---- MFMA #2: Z^T[e, o] = sum_f X[f, e] * W[o, f]; sample chains interleaved -------------
+            const f32x2 bn = *reinterpret_cast<const f32x2*>(p_bn + (nt * 16 + c) * 2);
+            f32x4 c2[SPW][EB];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const int q = s * NQ + j;
+                        const int row = 16 * (q >> 2) + 4 * g + (q & 3);
+                        const float a2 = xt[row * ES + 16 * eb + c];
+                        if (j == 0)
+                            c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), c2[s][eb], 0, 0, 0);
+                    }
+            // ---- epilogue: exp(z / S) = exp2(z * log2e / S) (rel. error <= ~|z| * 1.3e-7), BN affine, store
+            if (!dbg_no_store) {
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    if (b0 + s < Bi) {
+                        float* dst = a.out + ((size_t)(b0 + s) * O + 16 * nt + c) * (size_t)E + 4 * g;
 #pragma unroll
                         for (int eb = 0; eb < EB; ++eb) {
+                            const f32x4 z = c2[s][eb] * kexp[s];
                             f32x4 v;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaf(exp_accurate(c2[nt][eb][r]), sc[nt], sh[nt]);
+                            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_exp2f(z[r]);
+                            v = v * bn[0] + bn[1];
                             *reinterpret_cast<f32x4*>(dst + 16 * eb) = v;
                         }
                     }
                 }
+            } else {
+#pragma unroll
+                for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                    for (int eb = 0; eb < EB; ++eb) asm volatile("" ::"v"(c2[s][eb]));
             }
 #undef XG
+#undef XP_GET
+#undef XP_SET
+#undef VV
         }
     }
 }
@@ -380,25 +473,35 @@ struct MfmaShape { int E, NQ; };
 static constexpr MfmaShape kShapes[] = {{16, 10}, {64, 10}, {32, 6}};
 
 bool fused_mfma_supports(int F, int E, int O) {
-    if (O % 32 != 0) return false;
+    if (O % 16 != 0 || O > 256) return false;
     const int nq = (F + 3) / 4;
     for (const auto& s : kShapes)
         if (s.E == E && s.NQ == nq) return true;
     return false;
 }
 
+#ifndef ARMNET_WPS
+#define ARMNET_WPS 4
+#endif
+
 template <int E, int NQ, int MODE, int SRC>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
-    constexpr int NTC = 2;
     constexpr int SPW = 4 / cgcd(NQ, 4);
-    constexpr int NTILE = SPW * NQ / 4;
-    constexpr size_t lds = (size_t)4 * NTILE * 16 * (E + 4) * sizeof(float);
+    constexpr int WPS = (E >= 64) ? 2 : ARMNET_WPS;
+    constexpr int NTILE = (SPW * NQ + 3) / 4;
+    const int NT = a.O / 16;
+    const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +
+                        (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32) * sizeof(float);
+    if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
     const int64_t ngroups = (a.B + SPW - 1) / SPW;
-    int64_t blocks = (ngroups + 3) / 4;
-    const int64_t resident = 256 * (lds > 40 * 1024 ? 1 : 2);    // blocks the chip holds at once
+    const int64_t blocks = (ngroups + 3) / 4;
+    int per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > WPS) per_cu = WPS;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = 256 * (int64_t)per_cu;              // blocks the chip holds at once
     // persistent grid-stride waves: the software pipeline's prologue is paid once per wave
     const int64_t want = blocks < resident ? blocks : resident;
-    auto kern = fused_mfma_kernel<E, NQ, NTC, MODE, SRC>;
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -420,7 +523,7 @@ static int launch_mode(const FusedArgs& a, hipStream_t st) {
 
 int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
-    if (a.B >= ((int64_t)1 << 31) / a.F) return ARMNET_ERR_UNSUPPORTED;   // 32-bit sample*field indices
+    if (a.B * a.F >= ((int64_t)1 << 29)) return ARMNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into ids/vals
     if (!fused_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (((uintptr_t)a.out | (uintptr_t)a.q_fold | (uintptr_t)(a.rows ? a.rows : a.table)) % 16) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (a.F + 3) / 4;
