@@ -100,9 +100,25 @@ class ArmNetBase(nn.Module):
         bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
         qf, sc, sh = self._folded.get(self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), bw, at.query,
                                       self.arm_bn)
+        if getattr(self, "_shard", None) is not None:
+            from .sharded import sharded_arm_block
+            return sharded_arm_block(self._shard, ids, vals, qf, at.values, sc, sh, self.alpha, n_iter=self.n_iter,
+                                     write_clamped_vals=True, flags=self.kernel_flags)
         return arm_block_forward(ids, vals, self.embedding.embedding.weight, qf, at.values, sc, sh, self.alpha,
                                  n_iter=self.n_iter, write_clamped_vals=True, check_ids=self.check_ids,
                                  flags=self.kernel_flags)
+
+    def shard_embedding(self, group=None):
+        """Row-shard the ARM embedding table over the process group (multi-GPU): this rank
+        keeps rows i = rank (mod world); every later arm_block() call fetches rows by all-to-all.
+        The full table must be resident when this is called (it is released afterwards)."""
+        import torch.distributed as dist
+        from .sharded import RowShardedTable, shard_rows
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        w = self.embedding.embedding.weight.detach()
+        self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group)
+        return self
 
     def forward(self, x, vals=None):
         """x = {'id': Long[B,F], 'value': Float[B,F], ...} -> logits Float[B] (armnet_1h.py:76-98).

@@ -24,7 +24,7 @@ F_WRITE_CLAMPED_VALS, F_FAITHFUL_BISECT, F_FORCE_GENERIC = 0x1, 0x2, 0x4
 EXPORTS = (
     "armnet_abi_version", "armnet_strerror", "armnet_last_hip_error", "armnet_fold_params_f32",
     "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
-    "armnet_clamp_vals_f32", "armnet_entmax_f32",
+    "armnet_clamp_vals_f32", "armnet_entmax_f32", "armnet_shard_route_ws_bytes", "armnet_shard_route_ids",
 )
 
 _lib = None
@@ -56,6 +56,7 @@ def load():
         if not hasattr(lib, name):
             raise ArmnetNativeError(f"{LIB_PATH} does not export {name}")
     lib.armnet_strerror.restype = ctypes.c_char_p
+    lib.armnet_shard_route_ws_bytes.restype = ctypes.c_int64
     lib.armnet_last_hip_error.restype = ctypes.c_char_p
     if lib.armnet_abi_version() != ABI_VERSION:
         raise ArmnetNativeError(f"ABI version mismatch: library {lib.armnet_abi_version()} != binding {ABI_VERSION}")
@@ -152,3 +153,19 @@ def entmax(rows, d, alpha, n_iter, ensure_sum_one, flags, X, P):
     _dev_f32(X, "X"); _dev_f32(P, "P")
     check(load().armnet_entmax_f32(ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
                                    int(bool(ensure_sum_one)), ctypes.c_uint32(flags), _ptr(X), _ptr(P), _stream()))
+
+
+def shard_route_ws_bytes(n, R):
+    return int(load().armnet_shard_route_ws_bytes(ctypes.c_int64(n), int(R)))
+
+
+def shard_route_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_status=None):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    for name, t in (("counts", counts), ("send_local", send_local), ("perm", perm)):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise ArmnetNativeError(f"{name}: expected a contiguous int32 tensor on the HIP device")
+    check(load().armnet_shard_route_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat),
+                                        _ptr(counts), _ptr(send_local), _ptr(perm), _ptr(workspace),
+                                        ctypes.c_int64(workspace.numel() * workspace.element_size()),
+                                        _ptr(id_status), _stream()))

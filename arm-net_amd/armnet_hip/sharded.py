@@ -1,0 +1,92 @@
+"""Row-sharded embedding lookup over RCCL (no reference counterpart — SURVEY.md §8e).
+
+Rank r of R owns the table rows ``{i : i % R == r}`` (local index ``i // R``; the modulo partition
+balances skewed ids).  One lookup of a rank's ``ids [B, F]``:
+
+    route      armnet_shard_route_ids: counting sort of the B*F ids by owner          (HIP, this rank)
+    exchange   all_gather of the R counts  ->  every rank knows the R x R split matrix (tiny)
+    exchange   all_to_all_single of int32 local row indices                             (RCCL over xGMI)
+    gather     armnet_gather_scale_f32(vals=NULL): owner reads its rows                 (HIP, HBM-bound)
+    exchange   all_to_all_single of the rows (E*4 bytes per id)                         (RCCL over xGMI)
+    consume    armnet_fused_fwd_f32 with table = received rows, ids = perm (int32)      (no un-permute pass)
+
+The arithmetic of the fused block is untouched: the sharded result is bit-equal to the single-GPU one.
+`ops` abstracts the two device kernels so that the routing logic can be exercised by world_size-2
+gloo tests on CPU with a test double (tests/test_sharded_gloo.py); the product default is HipShardOps.
+"""
+import torch
+import torch.distributed as dist
+
+from . import native
+
+
+class HipShardOps:
+    """Device kernels of the sharded lookup (C ABI).  CPU tensors are rejected by the binding."""
+
+    def route(self, ids_flat, R, nfeat):
+        n = ids_flat.numel()
+        dev = ids_flat.device
+        counts = torch.empty(R, device=dev, dtype=torch.int32)
+        send_local = torch.empty(n, device=dev, dtype=torch.int32)
+        perm = torch.empty(n, device=dev, dtype=torch.int32)
+        ws = torch.empty(max(native.shard_route_ws_bytes(n, R), 4), device=dev, dtype=torch.uint8)
+        native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws)
+        return counts, send_local, perm
+
+    def gather(self, local_idx, table_local):
+        out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
+        if local_idx.numel():
+            native.gather_scale(local_idx.numel(), table_local.shape[1], local_idx, None, table_local, out)
+        return out
+
+
+def shard_rows(full_table, rank, world):
+    """Local shard of a full [nfeat, E] table under the modulo partition."""
+    return full_table[rank::world].contiguous()
+
+
+class RowShardedTable:
+    """One rank's shard of the embedding table + the lookup protocol above."""
+
+    def __init__(self, table_local, nfeat, group=None, ops=None):
+        self.table_local = table_local
+        self.nfeat = int(nfeat)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ops = ops if ops is not None else HipShardOps()
+        expect = (self.nfeat - self.rank + self.world - 1) // self.world
+        if table_local.shape[0] != expect:
+            raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
+
+    def lookup(self, ids):
+        """ids [B, F] (this rank's samples) -> (rows [B*F, E] in send order, perm [B*F] int32)."""
+        R = self.world
+        flat = ids.reshape(-1).contiguous()
+        n = flat.numel()
+        counts, send_local, perm = self.ops.route(flat, R, self.nfeat)
+        E = self.table_local.shape[1]
+        if R == 1:
+            return self.ops.gather(send_local, self.table_local), perm
+        # split matrix: row q = what rank q sends to each owner
+        allc = torch.empty(R * R, device=counts.device, dtype=torch.int32)
+        dist.all_gather_into_tensor(allc, counts, group=self.group)
+        m = allc.view(R, R).cpu()                      # the one host sync of the step
+        send_counts = m[self.rank].tolist()
+        recv_counts = m[:, self.rank].tolist()
+        recv_idx = torch.empty(sum(recv_counts), device=flat.device, dtype=torch.int32)
+        dist.all_to_all_single(recv_idx, send_local, recv_counts, send_counts, group=self.group)
+        rows_out = self.ops.gather(recv_idx, self.table_local)
+        rows_in = torch.empty(n, E, device=flat.device, dtype=torch.float32)
+        dist.all_to_all_single(rows_in, rows_out, send_counts, recv_counts, group=self.group)
+        return rows_in, perm
+
+
+def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
+                      write_clamped_vals=True, flags=0):
+    """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E]."""
+    from .block import arm_block_forward
+    rows, perm = shard.lookup(ids)
+    B, F = vals.shape
+    return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
+                             n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags)

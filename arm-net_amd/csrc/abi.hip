@@ -113,4 +113,19 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
     return launch_entmax(rows, d, cfg, X, P, (hipStream_t)stream);
 }
 
+int64_t armnet_shard_route_ws_bytes(int64_t n, int R) {
+    if (n < 0 || R < 1) return -1;
+    return (int64_t)shard_route_ws_bytes(n, R);
+}
+
+int armnet_shard_route_ids(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* counts,
+                           int32_t* send_local, int32_t* perm, void* workspace, int64_t ws_bytes,
+                           int32_t* id_status, void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || !counts || (n > 0 && (!ids || !send_local || !perm))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    return launch_shard_route(n, ids, id_type, R, nfeat, counts, send_local, perm, workspace, (size_t)ws_bytes,
+                              id_status, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -486,8 +486,9 @@ bool fused_mfma_supports(int F, int E, int O) {
 
 template <int E, int NQ, int MODE, int SRC>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
-    constexpr int SPW = 4 / cgcd(NQ, 4);
-    constexpr int WPS = (E >= 64) ? 2 : ARMNET_WPS;
+    // E = 64: one sample per group (48-row padded tile) keeps LDS at 14 KB/wave and the row prefetch at 48 VGPRs
+    constexpr int SPW = (E >= 64) ? 1 : 4 / cgcd(NQ, 4);
+    constexpr int WPS = (E >= 64) ? 3 : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = a.O / 16;
     const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +

@@ -47,19 +47,24 @@ def parse():
     ap.add_argument("--nhid", type=int, default=32)
     ap.add_argument("--nhead", type=int, default=1, help=">1 selects models.armnet (multi-head)")
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--shard", choices=["replicate", "rows"], default="replicate",
+                    help="rows = embedding table row-sharded over the ranks, all-to-all lookup (SURVEY §8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def build_model(a, device):
+def build_model(a, device, rank=0, world=1):
     torch.manual_seed(2025)                     # the reference's default seed (train.py:47)
+    # row-sharded runs never materialise the full table: the module gets a 16-row placeholder and the
+    # rank's shard is generated directly on the device below
+    nfeat_mod = 16 if a.shard == "rows" else a.nfeat
     if a.nhead == 1:
         from models.armnet_1h import ARMNetModel
-        m = ARMNetModel(a.nfield, a.nfeat, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, False, 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, False, 2, 256)
     else:
         from models.armnet import ARMNetModel
-        m = ARMNetModel(a.nfield, a.nfeat, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, False, 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, False, 2, 256)
     if a.regime == "stress":
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():
@@ -70,7 +75,16 @@ def build_model(a, device):
             m.arm_bn.running_var.copy_(torch.rand(m.arm_bn.running_var.shape, generator=g) * 1.5 + 0.5)
     m.eval()
     m.check_ids = False                         # no host sync inside the timed region
-    return m.to(device)
+    m = m.to(device)
+    if a.shard == "rows":
+        from armnet_hip.sharded import RowShardedTable
+        n_local = (a.nfeat - rank + world - 1) // world
+        bound = (6.0 / (a.nfeat + a.nemb)) ** 0.5 if a.regime == "fresh" else 0.87    # xavier-uniform / stress
+        gdev = torch.Generator(device=device).manual_seed(2025 + rank)
+        shard = (torch.rand(n_local, a.nemb, device=device, generator=gdev) * 2 - 1) * bound
+        m._shard = RowShardedTable(shard, a.nfeat, None)
+        m.nfeat = a.nfeat
+    return m
 
 
 def make_batch(a, rank, device):
@@ -133,7 +147,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    model = build_model(a, dev)
+    model = build_model(a, dev, rank, world)
     ids, vals, ids_cpu, vals_cpu = make_batch(a, rank, dev)
     O = a.nhead * a.nhid
 
@@ -180,7 +194,8 @@ def main():
                                    f"nfeat={a.nfeat} nemb={a.nemb} nhid={a.nhid} nhead={a.nhead} "
                                    f"alpha={a.alpha} B={a.batch}/GPU, ids {a.ids} int64, weights {a.regime}-init, "
                                    f"eval mode", "global_batch": world * a.batch,
-                       "parallelism": f"dp{world} (table replicated, no collective)"},
+                       "parallelism": (f"dp{world} (table replicated, no collective)" if a.shard == "replicate" else
+                                       f"dp{world} x row-sharded table (mod {world}), RCCL all-to-all lookup")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "armnet::fused_mfma_kernel", "kernel_ms": kernel_ms,
@@ -190,7 +205,7 @@ def main():
                              "ms_per_step": full_wall_ms / a.steps,
                              "note": "fused block + MLP head 2x256 (torch/hipBLASLt fp32) to logits"},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             line["cpu_baseline"] = cpu_baseline(a, model, ids_cpu, vals_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:

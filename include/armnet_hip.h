@@ -125,6 +125,20 @@ int armnet_clamp_vals_f32(float* vals, int64_t n, void* stream);
 int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_sum_one, uint32_t flags,
                       const float* X, float* P, void* stream);
 
+/*
+ * Routing step of the row-sharded embedding lookup (multi-GPU; no reference counterpart — the
+ * reference is single-device).  Rank r of R owns table rows {i : i % R == r},
+ * stored at local index i / R.  For n ids: counts[r] = ids owned by r; send_local[p] = local row
+ * index of the id at send position p (positions grouped by owner, deterministic); perm[i] = send
+ * position of id i.  The rows come back from the all-to-all in send order, so `perm` is exactly the
+ * int32 "ids" array with which armnet_fused_fwd_f32 indexes the received row buffer as its table.
+ * workspace: armnet_shard_route_ws_bytes(n, R) bytes of device memory (contents undefined).
+ */
+int64_t armnet_shard_route_ws_bytes(int64_t n, int R);
+int armnet_shard_route_ids(int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                           int32_t* counts, int32_t* send_local, int32_t* perm,
+                           void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,3 +148,39 @@ def test_attention_submodule_surface():
         with torch.no_grad():
             w = m.attn_layer(torch.from_numpy(ref["x_emb"]).to(DEV))
         assert _rel_err(w.cpu().numpy(), ref["arm_weight"]) <= TOL
+
+
+@pytest.mark.parametrize("R", [1, 2, 8])
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_shard_route_kernel_contract(R, dtype):
+    """armnet_shard_route_ids: counts, grouping by owner, local indices, perm is a permutation."""
+    from armnet_hip.sharded import HipShardOps
+    nfeat, n = 100003, 39 * 1237
+    ids = torch.randint(0, nfeat, (n,), generator=torch.Generator().manual_seed(R)).to(dtype)
+    counts, send_local, perm = HipShardOps().route(ids.to(DEV), R, nfeat)
+    counts, send_local, perm = counts.cpu().numpy(), send_local.cpu().numpy(), perm.cpu().numpy()
+    idn = ids.numpy().astype(np.int64)
+    np.testing.assert_array_equal(counts, np.bincount(idn % R, minlength=R))
+    assert sorted(perm.tolist()) == list(range(n))
+    owner_of_pos = np.repeat(np.arange(R), counts)
+    np.testing.assert_array_equal(owner_of_pos[perm], idn % R)
+    np.testing.assert_array_equal(send_local[perm], idn // R)
+    counts2, send2, perm2 = (t.cpu().numpy() for t in HipShardOps().route(ids.to(DEV), R, nfeat))
+    np.testing.assert_array_equal(perm, perm2)                    # deterministic
+
+
+@pytest.mark.parametrize("name", ["g2_criteo_1h_a2.0_stress", "g4_criteo_1h_e64_a1.7_stress", "g3_criteo_mh4_a2.0_stress"])
+def test_row_sharded_path_is_bit_equal_to_replicated(name):
+    """world_size 1 exercises route -> gather -> fused kernel over (rows, perm): sharding only moves rows,
+    so the result must equal the replicated-table result bit for bit (SURVEY.md §4 iii)."""
+    meta, sd, ids, vals, ref = load(name)
+    m = build_model(meta, sd, DEV)
+    g = torch.Generator().manual_seed(5)
+    B = 777
+    idt = torch.randint(0, meta["ctor"]["nfeat"], (B, meta["ctor"]["nfield"]), generator=g).to(DEV)
+    vt = torch.rand(B, meta["ctor"]["nfield"], generator=g).to(DEV)
+    with torch.no_grad():
+        want = m.arm_block(idt, vt.clone())
+        m.shard_embedding()
+        got = m.arm_block(idt, vt.clone())
+    assert torch.equal(got, want)
