@@ -142,11 +142,45 @@ class ArmNetBase(nn.Module):
 
 
 class _MLP(nn.Module):
-    """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*)."""
+    """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*).
+
+    Training mode runs the nn.Sequential as is.  In eval mode on the GPU each (Linear, BatchNorm1d, ReLU,
+    Dropout) group collapses to ONE hipBLASLt GEMM with a bias+ReLU epilogue: the BN affine is folded into
+    the Linear's weight and bias (W' = W * s, b' = b * s + t with s = gamma / sqrt(var + eps),
+    t = beta - mean * s; refreshed when any source tensor's version counter moves)."""
 
     def __init__(self, ninput, nlayers, nhid, dropout, noutput=1):
         super().__init__()
         self.mlp = build_mlp(ninput, nlayers, nhid, dropout, noutput)
+        self._fold_key = None
+        self._folded = None
+        self.fold_eval = True
+
+    def _fold(self):
+        mods = list(self.mlp)
+        src = [p for m in mods for p in list(m.parameters()) + list(m.buffers())]
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if key != self._fold_key:
+            layers = []
+            i = 0
+            with torch.no_grad():
+                while i < len(mods):
+                    lin = mods[i]
+                    if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                        bn = mods[i + 1]
+                        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                        t = bn.bias - bn.running_mean * s
+                        layers.append(((lin.weight * s[:, None]).t().contiguous(), lin.bias * s + t, True))
+                        i += 4                          # Linear, BatchNorm1d, ReLU, Dropout
+                    else:
+                        layers.append((lin.weight.t().contiguous(), lin.bias.clone(), False))
+                        i += 1
+            self._folded, self._fold_key = layers, key
+        return self._folded
 
     def forward(self, x):
-        return self.mlp(x)
+        if self.training or not x.is_cuda or not self.fold_eval:
+            return self.mlp(x)
+        for wt, b, relu in self._fold():
+            x = torch._addmm_activation(b, x, wt) if relu else torch.addmm(b, x, wt)
+        return x

@@ -66,7 +66,7 @@ class RowShardedTable:
         n = flat.numel()
         counts, send_local, perm = self.ops.route(flat, R, self.nfeat)
         E = self.table_local.shape[1]
-        if R == 1:
+        if R == 1 and not dist.is_initialized():
             return self.ops.gather(send_local, self.table_local), perm
         # split matrix: row q = what rank q sends to each owner
         allc = torch.empty(R * R, device=counts.device, dtype=torch.int32)

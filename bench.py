@@ -47,8 +47,10 @@ def parse():
     ap.add_argument("--nhid", type=int, default=32)
     ap.add_argument("--nhead", type=int, default=1, help=">1 selects models.armnet (multi-head)")
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
-    ap.add_argument("--shard", choices=["replicate", "rows"], default="replicate",
-                    help="rows = embedding table row-sharded over the ranks, all-to-all lookup (SURVEY §8e)")
+    ap.add_argument("--shard", choices=["replicate", "rows", "both"], default=None,
+                    help="replicate = every rank holds the table (no collective); rows = table row-sharded over "
+                         "the ranks, RCCL all-to-all lookup (SURVEY §8e); both (default when N > 1) = value from "
+                         "replicate plus a row_sharded object measured in the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -139,9 +141,12 @@ def cpu_baseline(a, model, ids_cpu, vals_cpu):
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.shard is None:
+        a.shard = "both" if world > 1 else "replicate"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("ARMNET_BENCH_FORCE_DIST"))   # FORCE: exercise RCCL with 1 rank
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local)
@@ -153,7 +158,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,10 +176,19 @@ def main():
     wall_ms, ev_ms = timed(step_block, a.steps, sync_all)
     full_wall_ms, _ = timed(step_full, a.steps, sync_all)
 
-    t = torch.tensor([wall_ms, ev_ms, full_wall_ms], device=dev, dtype=torch.float64)
-    if world > 1:
+    sharded_ms = float("nan")
+    if a.shard == "both":
+        # same model, same batch, but the table row-sharded over the ranks and fetched by all-to-all
+        model.shard_embedding()
+        for _ in range(a.warmup):
+            step_block()
+        sharded_ms, _ = timed(step_block, a.steps, sync_all)
+        model._shard = None
+
+    t = torch.tensor([wall_ms, ev_ms, full_wall_ms, sharded_ms], device=dev, dtype=torch.float64)
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_ms, ev_ms, full_wall_ms = t.tolist()
+    wall_ms, ev_ms, full_wall_ms, sharded_ms = t.tolist()
 
     if rank == 0:
         ms_per_step = wall_ms / a.steps
@@ -194,7 +208,7 @@ def main():
                                    f"nfeat={a.nfeat} nemb={a.nemb} nhid={a.nhid} nhead={a.nhead} "
                                    f"alpha={a.alpha} B={a.batch}/GPU, ids {a.ids} int64, weights {a.regime}-init, "
                                    f"eval mode", "global_batch": world * a.batch,
-                       "parallelism": (f"dp{world} (table replicated, no collective)" if a.shard == "replicate" else
+                       "parallelism": (f"dp{world} (table replicated, no collective)" if a.shard != "rows" else
                                        f"dp{world} x row-sharded table (mod {world}), RCCL all-to-all lookup")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -205,10 +219,18 @@ def main():
                              "ms_per_step": full_wall_ms / a.steps,
                              "note": "fused block + MLP head 2x256 (torch/hipBLASLt fp32) to logits"},
         }
+        if a.shard == "both":
+            line["row_sharded"] = {
+                "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
+                "ms_per_step": sharded_ms / a.steps,
+                "note": f"same block with the table row-sharded (row i on rank i mod {world}): HIP counting-sort "
+                        f"routing, all_to_all_single of int32 row indices, owner-side gather, all_to_all_single of "
+                        f"{a.nemb * 4}-byte rows ({(world - 1) / world:.0%} of {a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB "
+                        f"per rank per step cross xGMI), fused kernel over (rows, perm)"}
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             line["cpu_baseline"] = cpu_baseline(a, model, ids_cpu, vals_cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
