@@ -138,6 +138,18 @@ def cpu_baseline(a, model, ids_cpu, vals_cpu):
                       f"oracle_arm_block (50-step bisection, OpenMP, {threads} threads)"}
 
 
+def pmc_traffic(a):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), when they were taken on
+    exactly this workload; None otherwise (counters cannot be read from inside the timed process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        key = f"nfield={a.nfield} nemb={a.nemb} nhid={a.nhid} nhead={a.nhead} B={a.batch} alpha={a.alpha} ids={a.ids}"
+        return t["traffic_bytes_per_launch"] if t["workload"] == key else None
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,7 +223,7 @@ def main():
                        "parallelism": (f"dp{world} (table replicated, no collective)" if a.shard != "rows" else
                                        f"dp{world} x row-sharded table (mod {world}), RCCL all-to-all lookup")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a),
                          "kernel": "armnet::fused_mfma_kernel", "kernel_ms": kernel_ms,
                          "alg_bytes_per_sample": read_b + write_b,
                          "folded_tflops": 4 * O * a.nfield * a.nemb * a.batch / (kernel_ms * 1e-3) / 1e12},
