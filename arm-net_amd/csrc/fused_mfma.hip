@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
-    uint32_t sfo[NI];    // s*F + f of the row this lane stages in instruction n (0 for a pad row)
+    uint32_t off4[NI];   // 4 * (s*F + f) of the row this lane stages in instruction n (0 for a pad row)
     bool pad[NI];        // pad row: stages zeros
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         const int s = q / NQ, j = q - s * NQ;
         const int f = 4 * j + (i >> 2);
         pad[n] = !(q < NQT && f < F);
-        sfo[n] = pad[n] ? 0u : (uint32_t)(s * F + f);
+        off4[n] = pad[n] ? 0u : 4u * (uint32_t)(s * F + f);
     }
     const float padneg = ((4 * (NQ - 1) + g) >= F) ? -INFINITY : 0.f;   // added to this lane's last gate
     const bool write_vals = (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) != 0;
@@ -168,55 +168,68 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const bool dbg_no_solve = (a.flags & 0x100u) != 0;   // skip the Newton iterations
     const bool dbg_hot_rows = (a.flags & 0x200u) != 0;   // fold ids into 1024 rows (cache-resident gather)
     const bool dbg_no_store = (a.flags & 0x400u) != 0;   // skip the output stores
+    const bool dbg_no_mfma = (a.flags & 0x800u) != 0;    // replace the MFMAs by register copies
     const uint32_t id_mask = dbg_hot_rows ? 1023u : 0xffffffffu;
     const uint32_t id_max = (uint32_t)a.nfeat - 1u;
     const char* row_base = reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) + chunk * 16;
+    const uint32_t out_lane_off = (uint32_t)((c * E + 4 * g) * 4);
+    const uint32_t F4 = 4u * (uint32_t)F;
 
     // ---- software pipeline -------------------------------------------------------------------------
     // iteration k:  stage rows(k) -> LDS | range-check ids(k+1), issue row + value loads(k+1)
     //               | issue RAW id loads(k+2) | compute(k).  Nothing loaded in an iteration is looked at
-    //               before the next one.  Groups past the end re-read the last group (results unused).
+    //               before the next one.  All per-group addressing is scalar base (SALU) + a per-lane
+    //               constant offset; groups past the end re-read the last group, and in a short last
+    //               group the lanes of the missing sample re-read sample 0 (results never stored).
     f32x4 rows_cur[NI];
     float val_cur[NI];
     uint32_t raw_lo[NI], raw_hi[NI];
 
-    auto elem_index = [&](int gidx, int n) -> uint32_t {
-        // element (sample, field) index, clamped into the arrays: a short last group re-reads valid memory
-        const int gc = gidx < ngroups ? gidx : ngroups - 1;                  // SALU
-        const uint32_t idx = (uint32_t)(gc * SPW) * (uint32_t)F + sfo[n];
-        return min(idx, BF - 1u);
+    auto lane_off = [&](int n, bool short_grp) -> uint32_t {
+        return (short_grp && off4[n] >= F4) ? off4[n] - F4 : off4[n];
     };
     auto fetch_raw = [&](int gidx) {
         if constexpr (!FROM_ROWS) {
+            const int gc = gidx < ngroups ? gidx : ngroups - 1;
+            const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
+            const bool short_grp = gc * SPW + SPW > Bi;              // wave-uniform, true at most once
+            const char* ids_g = reinterpret_cast<const char*>(a.ids) + (size_t)e0 * (SRC == 0 ? 8 : 4);
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                const uint32_t idx = elem_index(gidx, n);
+                const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
                 if constexpr (SRC == 0) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.ids) + (size_t)(idx * 8u));
+                    const uint2 w = *reinterpret_cast<const uint2*>(ids_g + (o << 1));
                     raw_lo[n] = w.x;
                     raw_hi[n] = w.y;
                 } else {
-                    raw_lo[n] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.ids) + (size_t)(idx * 4u));
+                    raw_lo[n] = *reinterpret_cast<const uint32_t*>(ids_g + o);
                     raw_hi[n] = 0u;
                 }
             }
         }
     };
     auto issue_rows_vals = [&](int gidx) {
+        const int gc = gidx < ngroups ? gidx : ngroups - 1;
+        const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
+        const bool short_grp = gc * SPW + SPW > Bi;
+        const char* vals_g = reinterpret_cast<const char*>(a.vals) + (size_t)e0 * 4;
+        if constexpr (!FROM_ROWS) {
+            if (check_ids) {                                         // wave-uniform branch
+                bool bad = false;
+#pragma unroll
+                for (int n = 0; n < NI; ++n) bad |= !pad[n] && (raw_hi[n] != 0u || raw_lo[n] > id_max);
+                if (bad && chunk == 0) atomicOr(a.id_status, 1);
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            const uint32_t idx = elem_index(gidx, n);
-            val_cur[n] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.vals) + (size_t)(idx * 4u));
+            const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
+            val_cur[n] = *reinterpret_cast<const float*>(vals_g + o);
             const char* src;
             if constexpr (FROM_ROWS) {
-                src = row_base + (size_t)idx * (size_t)(E * 4);
+                src = row_base + ((size_t)e0 * 4 + o) * (size_t)E;
             } else {
-                uint32_t id = raw_lo[n];
-                if (check_ids) {                                   // wave-uniform
-                    const bool bad = !pad[n] && (raw_hi[n] != 0u || id > id_max);
-                    if (bad && chunk == 0) atomicOr(a.id_status, 1);
-                }
-                id = (id < id_max ? id : id_max) & id_mask;       // memory-safe even when unchecked
+                const uint32_t id = min(raw_lo[n], id_max) & id_mask;   // memory-safe even when unchecked
                 src = row_base + (size_t)id * (size_t)(E * 4);
             }
             rows_cur[n] = *reinterpret_cast<const f32x4*>(src);
@@ -226,6 +239,14 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     fetch_raw(grp);
     issue_rows_vals(grp);
     fetch_raw(grp + nwaves);
+#ifdef ARMNET_PHASE_TIMING
+    // developer build: per-phase s_memtime deltas, summed over all waves into id_status[0..7] (as uint32)
+    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#define PHASE(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ph_acc[i] += _n - ph_t; ph_t = _n; } while (0)
+#else
+#define PHASE(i) do {} while (0)
+#endif
 
     const float am1 = a.cfg.am1;
     const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
@@ -237,24 +258,34 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         const int b0 = grp * SPW;
         // ---- stage the current group's rows (scaled) into the wave's LDS tile -----------------------
         wave_lds_fence();
+        bool changed = false;
+        float vcl[NI];
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            // clamp (armnet_1h.py:81; NaN stays NaN), optional write-back of the clamp, scale (layers.py:21)
+            // clamp (armnet_1h.py:81; NaN stays NaN), scale (layers.py:21)
             const float vraw = val_cur[n];
             float v = __builtin_amdgcn_fmed3f(vraw, 1e-3f, 1.0f);
             v = (vraw != vraw) ? vraw : v;
-            if (write_vals && v != vraw && chunk == 0 && !pad[n]) {
-                const uint32_t idx = (uint32_t)b0 * (uint32_t)F + sfo[n];
-                if (idx < BF) a.vals[idx] = v;
-            }
+            vcl[n] = v;
+            changed |= (v != vraw) && !pad[n];
             const f32x4 r = rows_cur[n] * (pad[n] ? 0.f : v);       // pad rows stage zeros
             const int row = n * RPI + lane / CH;
             *reinterpret_cast<f32x4*>(xt + row * ES + chunk * 4) = r;
+        }
+        // the reference's in-place clamp_: rare (a value outside [1e-3, 1]), so one wave-uniform test
+        if (write_vals && __builtin_amdgcn_ballot_w64(changed)) {
+            const uint32_t e0 = (uint32_t)b0 * (uint32_t)F;
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t idx = e0 + (off4[n] >> 2);
+                if (vcl[n] != val_cur[n] && chunk == 0 && !pad[n] && idx < BF) a.vals[idx] = vcl[n];
+            }
         }
         // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
         issue_rows_vals(grp + nwaves);
         fetch_raw(grp + 2 * nwaves);
         wave_lds_fence();
+        PHASE(0);
 
         for (int nt = 0; nt < NT; ++nt) {
             // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
@@ -266,6 +297,11 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 #pragma unroll
                 for (int t = 0; t < NTILE; ++t)
                     av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                if (dbg_no_mfma) {
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) c1[t] = av[t] * bq;
+                    continue;
+                }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -276,6 +312,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                             c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
+            PHASE(1);
             // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
 #define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]
 #define XP_GET(s, jp) (f32x2{XG(s, 2 * (jp)), XG(s, 2 * (jp) + 1)})
@@ -327,6 +364,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 }
                 Ssum[s] = 1.0f;
             }
+            PHASE(2);
             if constexpr (MODE == SOLVE_SOFTMAX) {
                 wave_lds_fence();
 #pragma unroll
@@ -395,6 +433,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                     }
                     if (!__builtin_amdgcn_ballot_w64(any_active)) break;
                 }
+                PHASE(3);
                 // unnormalised weights p * values (armnet_1h.py:34)
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
@@ -434,18 +473,24 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                         const int q = s * NQ + j;
                         const int row = 16 * (q >> 2) + 4 * g + (q & 3);
                         const float a2 = xt[row * ES + 16 * eb + c];
+                        if (dbg_no_mfma) {
+                            const float w = a2 * XG(s, j);
+                            c2[s][eb] = j == 0 ? f32x4{w, w, w, w} : c2[s][eb] + w;
+                            continue;
+                        }
                         if (j == 0)
                             c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                         else
                             c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), c2[s][eb], 0, 0, 0);
                     }
+            PHASE(4);
             // ---- epilogue: exp(z / S) = exp2(z * log2e / S) (rel. error <= ~|z| * 1.3e-7), BN affine, store
             if (!dbg_no_store) {
                 const f32x2 bn0 = {bn[0], bn[0]}, bn1 = {bn[1], bn[1]};
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
                     if (b0 + s < Bi) {
-                        float* dst = a.out + ((size_t)(b0 + s) * O + 16 * nt + c) * (size_t)E + 4 * g;
+                        char* dst = reinterpret_cast<char*>(a.out) + ((size_t)(b0 + s) * O + 16 * nt) * (size_t)(E * 4) + out_lane_off;
                         const f32x2 ke = {kexp[s], kexp[s]};
 #pragma unroll
                         for (int eb = 0; eb < EB; ++eb) {
@@ -455,7 +500,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                             const f32x2 ehi = {__builtin_amdgcn_exp2f(zhi[0]), __builtin_amdgcn_exp2f(zhi[1])};
                             const f32x2 vlo = __builtin_elementwise_fma(elo, bn0, bn1);
                             const f32x2 vhi = __builtin_elementwise_fma(ehi, bn0, bn1);
-                            *reinterpret_cast<f32x4*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
+                            *reinterpret_cast<f32x4*>(dst + 64 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
                         }
                     }
                 }
@@ -469,8 +514,13 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 #undef XP_GET
 #undef XP_SET
 #undef VV
+            PHASE(5);
         }
     }
+#ifdef ARMNET_PHASE_TIMING
+    if (lane == 0 && a.id_status)
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned int*>(a.id_status) + i, (unsigned int)(ph_acc[i] >> 4));
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------

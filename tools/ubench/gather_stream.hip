@@ -1,0 +1,83 @@
+// gather_stream.hip — memory-only floor of the fused block's access pattern on MI355X:
+// per sample read 39 int64 ids + 39 f32 vals, gather 39 random 64-B rows from a 64 MB table, write 2 KiB.
+// No math beyond one add per loaded row (keeps the loads live).  Variants: persistent waves with
+// 1..3 groups of loads in flight.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int DEPTH>
+__global__ void __launch_bounds__(256) k(const long long* ids, const float* vals, const float* table, float* out,
+                                         int B, int F, int do_store) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    const int chunk = lane & 3, r = lane >> 2;            // 16 rows per instruction, 4 lanes per row
+    // group = 2 samples = 78 rows -> 5 instructions (last partially used)
+    const int ngroups = B / 2;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int g = blockIdx.x * 4 + wave; g < ngroups; g += nw * DEPTH) {
+        f32x4 rows[DEPTH][5];
+        float vv[DEPTH][5];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int gg = g + d * nw < ngroups ? g + d * nw : ngroups - 1;
+            const size_t e0 = (size_t)gg * 2 * F;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                int row = n * 16 + r; if (row >= 2 * F) row = 2 * F - 1;
+                const long long id = ids[e0 + row];
+                vv[d][n] = vals[e0 + row];
+                rows[d][n] = *reinterpret_cast<const f32x4*>(table + (size_t)id * 16 + chunk * 4);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int gg = g + d * nw;
+            f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+            for (int n = 0; n < 5; ++n) s += rows[d][n] * vv[d][n];
+            acc += s;
+            if (do_store && gg < ngroups) {
+                // 2 samples x 2 KiB = 4 stores of 1 KiB per wave
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(out + (size_t)gg * 1024 + q * 256 + lane * 4) = s + (float)q;
+            }
+        }
+    }
+    if (acc[0] == 12345.f) out[0] = acc[1];
+}
+
+int main() {
+    const int B = 65536, F = 39, NF = 1000000;
+    std::vector<long long> h_ids((size_t)B * F);
+    srand(1);
+    for (auto& x : h_ids) x = ((long long)rand() * 32768 + rand()) % NF;
+    long long* ids; float *vals, *table, *out;
+    hipMalloc(&ids, h_ids.size() * 8); hipMalloc(&vals, h_ids.size() * 4);
+    hipMalloc(&table, (size_t)NF * 64); hipMalloc(&out, (size_t)B * 2048);
+    hipMemcpy(ids, h_ids.data(), h_ids.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(vals, 0, h_ids.size() * 4); hipMemset(table, 0, (size_t)NF * 64);
+    const double bytes_rd = (double)B * F * (8 + 4 + 64), bytes_wr = (double)B * 2048;
+    auto run = [&](auto kern, int blocks, int st, const char* name) {
+        for (int i = 0; i < 3; ++i) kern<<<blocks, 256>>>(ids, vals, table, out, B, F, st);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) kern<<<blocks, 256>>>(ids, vals, table, out, B, F, st);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+        printf("%-34s blocks=%5d store=%d : %7.1f us  %6.0f GB/s\n", name, blocks, st, ms * 1e3,
+               (bytes_rd + (st ? bytes_wr : 0)) / ms / 1e6);
+    };
+    for (int st : {1, 0}) {
+        for (int blocks : {512, 1024, 2048, 4096}) {
+            run(k<1>, blocks, st, "depth1 (1 group of loads in flight)");
+            run(k<2>, blocks, st, "depth2");
+            run(k<3>, blocks, st, "depth3");
+        }
+    }
+    return 0;
+}
