@@ -12,6 +12,66 @@ from . import native
 from .block import ArmBlockParams, _require_cuda, arm_block_forward, embedding_forward, entmax_forward
 
 
+class _GatherScaleFn(torch.autograd.Function):
+    """table[ids] * vals with a dense table gradient (what nn.Embedding + multiply gives the reference)."""
+
+    @staticmethod
+    def forward(ctx, table, ids, vals, check_ids):
+        ctx.save_for_backward(ids, vals)
+        ctx.nfeat = table.shape[0]
+        return embedding_forward(ids, vals, table, check_ids=check_ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, vals = ctx.saved_tensors
+        E = g.shape[-1]
+        d_table = torch.zeros(ctx.nfeat, E, device=g.device, dtype=g.dtype)
+        d_table.index_add_(0, ids.reshape(-1), (g * vals.unsqueeze(-1)).reshape(-1, E))
+        return d_table, None, None, None
+
+
+class _ArmBlockFn(torch.autograd.Function):
+    """Pre-BatchNorm exponential neurons z [B,O,E] with the HIP forward (identity affine) and the HIP
+    backward (armnet_fused_bwd_f32); BatchNorm1d and the MLP head stay with torch autograd."""
+
+    @staticmethod
+    def forward(ctx, table, bilinear_w, query, values, ids, vals, cfg):
+        variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
+        dev = query.device
+        O = K * H
+        qf = torch.empty(O, E, device=dev, dtype=torch.float32)
+        one, zero = torch.ones(O, device=dev), torch.zeros(O, device=dev)
+        sc, sh = torch.empty(O, device=dev), torch.empty(O, device=dev)
+        native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
+                           one, zero, zero, one, 0.0, qf, sc, sh)
+        z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
+                              write_clamped_vals=True, check_ids=check_ids, flags=flags)
+        ctx.save_for_backward(table, bilinear_w, query, values, ids, vals, qf, z)
+        ctx.cfg = cfg
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        table, bilinear_w, query, values, ids, vals, qf, z = ctx.saved_tensors
+        variant, K, H, E, D, alpha, n_iter, flags, _ = ctx.cfg
+        B, F = vals.shape
+        O = K * H
+        d_table = torch.zeros_like(table)
+        d_values = torch.zeros(O, F, device=dz.device, dtype=torch.float32)
+        d_qf = torch.zeros(O, E, device=dz.device, dtype=torch.float32)
+        native.fused_bwd(B, F, E, O, alpha, n_iter, flags, ids.contiguous(), vals, table.detach(), qf,
+                         values.detach().reshape(O, F).contiguous(), z, dz.contiguous(), d_table, d_values, d_qf)
+        scale = float(D) ** -0.5
+        if variant == native.ONE_HEAD:                      # q_fold = scale * query @ W,  W = bilinear_w [D,E]
+            d_q = scale * (d_qf @ bilinear_w.t())
+            d_w = scale * (query.t() @ d_qf)
+        else:                                               # q_fold[k,o,e] = scale * sum_y W[k,e,y] query[k,o,y]
+            g3 = d_qf.view(K, H, E)
+            d_q = scale * torch.einsum("koe,key->koy", g3, bilinear_w)
+            d_w = scale * torch.einsum("koe,koy->key", g3, query)
+        return d_table, d_w, d_q, d_values.view_as(values), None, None, None
+
+
 class HipEmbedding(nn.Module):
     """Field embedding lookup scaled by the field value (reference: models/layers.py:8-21).
 
@@ -25,6 +85,8 @@ class HipEmbedding(nn.Module):
         self.check_ids = True
 
     def forward(self, x):
+        if torch.is_grad_enabled() and self.embedding.weight.requires_grad:
+            return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], self.check_ids)
         return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=self.check_ids)
 
 
@@ -89,15 +151,25 @@ class ArmNetBase(nn.Module):
         raise NotImplementedError
 
     def arm_block(self, ids, vals):
-        """ids [B,F], vals [B,F] (clamped in place) -> post-BN exponential neurons [B, O, E]."""
-        if self.training:
-            raise NotImplementedError(
-                "ARMNetModel (HIP): the training pass (batch-statistics BatchNorm + backward of the fused "
-                "block, SURVEY.md §8f-2) is not built yet; call model.eval().")
+        """ids [B,F], vals [B,F] (clamped in place) -> post-BN exponential neurons [B, O, E].
+
+        Inference (eval mode under no_grad, or frozen parameters): ONE fused kernel, BN folded.
+        Otherwise (training, or eval with autograd on): the same kernel yields the pre-BN neurons inside
+        an autograd.Function whose backward is armnet_fused_bwd_f32; arm_bn then runs as a torch module
+        (batch statistics + running-stat update in train mode, armnet_1h.py:85)."""
         _require_cuda(vals, "x['value']")
         _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
         at = self.attn_layer
         bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
+        needs_grad = torch.is_grad_enabled() and any(
+            p.requires_grad for p in (self.embedding.embedding.weight, bw, at.query, at.values))
+        if self.training or needs_grad:
+            if getattr(self, "_shard", None) is not None:
+                raise NotImplementedError("training with a row-sharded table is not supported")
+            cfg = (self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), self.alpha, self.n_iter,
+                   self.kernel_flags, self.check_ids)
+            z = _ArmBlockFn.apply(self.embedding.embedding.weight, bw, at.query, at.values, ids, vals, cfg)
+            return self.arm_bn(z)
         qf, sc, sh = self._folded.get(self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), bw, at.query,
                                       self.arm_bn)
         if getattr(self, "_shard", None) is not None:
@@ -179,8 +251,8 @@ class _MLP(nn.Module):
         return self._folded
 
     def forward(self, x):
-        if self.training or not x.is_cuda or not self.fold_eval:
-            return self.mlp(x)
+        if self.training or torch.is_grad_enabled() or not x.is_cuda or not self.fold_eval:
+            return self.mlp(x)                   # autograd / training: the plain nn.Sequential
         for wt, b, relu in self._fold():
             x = torch._addmm_activation(b, x, wt) if relu else torch.addmm(b, x, wt)
         return x

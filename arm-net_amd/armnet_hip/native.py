@@ -25,6 +25,7 @@ EXPORTS = (
     "armnet_abi_version", "armnet_strerror", "armnet_last_hip_error", "armnet_fold_params_f32",
     "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
     "armnet_clamp_vals_f32", "armnet_entmax_f32", "armnet_shard_route_ws_bytes", "armnet_shard_route_ids",
+    "armnet_fused_bwd_f32",
 )
 
 _lib = None
@@ -169,3 +170,15 @@ def shard_route_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_st
                                         _ptr(counts), _ptr(send_local), _ptr(perm), _ptr(workspace),
                                         ctypes.c_int64(workspace.numel() * workspace.element_size()),
                                         _ptr(id_status), _stream()))
+
+
+def fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, z, dz, d_table, d_values, d_qfold):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values), ("z", z), ("dz", dz),
+                 ("d_table", d_table), ("d_values", d_values), ("d_qfold", d_qfold)):
+        _dev_f32(t, n)
+    check(load().armnet_fused_bwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                      ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                      ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
+                                      _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))

@@ -126,6 +126,22 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
                       const float* X, float* P, void* stream);
 
 /*
+ * Backward of the fused block (training).  `z` is the forward's output computed with an
+ * identity BatchNorm affine (bn_scale = 1, bn_shift = 0: the pre-BN neurons of armnet_1h.py:85-86; the
+ * training-mode BatchNorm1d and the MLP stay with torch autograd), `dz` its gradient.  vals must already be
+ * clamped (the forward did it).  Accumulates (+=, caller zero-initialises):
+ *   d_table [nfeat,E]  dense gradient of the embedding table (x = table[id] * val, layers.py:20-21),
+ *   d_values [O,F]     gradient of attn_layer.values (armnet_1h.py:34),
+ *   d_qfold [O,E]      gradient of the folded query; the caller applies the chain rule of the fold to
+ *                      get d(query) and d(bilinear_w).
+ * The entmax Jacobian-vector product follows utils/entmax.py:70-80 (softmax when alpha == 1).
+ */
+int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                         const void* ids, int id_type, const float* vals, const float* table, int64_t nfeat,
+                         const float* q_fold, const float* values, const float* z, const float* dz,
+                         float* d_table, float* d_values, float* d_qfold, void* stream);
+
+/*
  * Routing step of the row-sharded embedding lookup (multi-GPU; no reference counterpart — the
  * reference is single-device).  Rank r of R owns table rows {i : i % R == r},
  * stored at local index i / R.  For n ids: counts[r] = ids owned by r; send_local[p] = local row

@@ -160,6 +160,37 @@ def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=
     _save(name, meta, sd_before, ids, vals, cap)
 
 
+def grad_case(name, variant, ctor, B, seed, train_mode):
+    """Gradients of the reference's own training step (train.py:60,108-113: BCEWithLogitsLoss, backward)
+    w.r.t. every parameter, for the backward of the fused block."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    if variant == "1h":
+        m = Ref1H(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["alpha"], ctor["nhid"], ctor["d_k"],
+                  ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"],
+                  ctor["deep_nlayer"], ctor["deep_nhid"])
+    else:
+        m = RefMH(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhead"], ctor["alpha"], ctor["nhid"],
+                  ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"],
+                  ctor["deep_nlayer"], ctor["deep_nhid"])
+    _stress(m, gen)
+    ids, vals = _inputs(B, ctor["nfield"], ctor["nfeat"], gen)
+    y = (torch.rand(B, generator=gen) > 0.5).float()
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.train(train_mode)
+    x = {"id": ids.clone(), "value": vals.clone()}
+    logits = m(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+    cap = {"logits": logits.detach().clone(), "loss": loss.detach().clone(), "vals_clamped": x["value"].clone(),
+           "target": y}
+    for k, p in m.named_parameters():
+        cap["grad/" + k] = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+    meta = dict(name=name, variant=variant, ctor=ctor, regime="stress", seed=seed, train=train_mode,
+                torch=torch.__version__)
+    _save(name, meta, sd_before, ids, vals, cap)
+
+
 def frappe_rows(n):
     ids, vals = [], []
     with open(os.path.join(REF, "data/frappe/test.libsvm")) as f:
@@ -247,6 +278,13 @@ def main():
                vals=torch.rand(1, 39, generator=torch.Generator().manual_seed(6)))
     # train mode (batch-statistics BN, armnet_1h.py:85 with nn.BatchNorm1d in training)
     model_case("g8_train_1h_a1.7_stress", "1h", base(39, 512, 16, 1.7, 32), 32, 71, "stress", train=True)
+    # gradients of one training step: train-mode BN and eval-mode BN
+    for alpha in (1.0, 1.5, 1.7, 2.0):
+        grad_case(f"h1_grad_1h_a{alpha}_train", "1h", base(39, 256, 16, alpha, 32, mlp_nhid=16), 24, 81, True)
+    grad_case("h1_grad_1h_a1.7_evalbn", "1h", base(39, 256, 16, 1.7, 32, mlp_nhid=16), 24, 82, False)
+    grad_case("h1_grad_mh2_a1.7_train", "mh", base(13, 128, 8, 1.7, 8, nhead=2, mlp_nhid=16), 16, 83, True)
+    grad_case("h1_grad_1h_ens_a2.0_train", "1h", base(22, 128, 32, 2.0, 32, ensemble=True, mlp_nhid=16, deep_nhid=16),
+              16, 84, True)
     entmax_cases()
 
 

@@ -12,6 +12,10 @@ def model_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g[0-57-9]*.npz")))
 
 
+def grad_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "h1_grad_*.npz")))
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())

@@ -109,8 +109,16 @@ def test_embedding_layer_matches_reference():
     emb = Embedding(meta["ctor"]["nfeat"], meta["ctor"]["nemb"])
     emb.load_state_dict({"embedding.weight": torch.from_numpy(sd["embedding.embedding.weight"])})
     emb = emb.to(DEV)
-    out = emb({"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(ref["vals_clamped"]).to(DEV)})
+    x = {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(ref["vals_clamped"]).to(DEV)}
+    with torch.no_grad():
+        out = emb(x)
     np.testing.assert_array_equal(out.cpu().numpy(), ref["x_emb"])     # gather * value: bit exact
+    out2 = emb(x)                                                      # autograd path: same forward, dense table grad
+    out2.sum().backward()
+    np.testing.assert_array_equal(out2.detach().cpu().numpy(), ref["x_emb"])
+    want = torch.zeros_like(emb.embedding.weight).index_add_(0, x["id"].reshape(-1),
+                                                              x["value"].reshape(-1, 1).expand(-1, out.shape[-1]))
+    torch.testing.assert_close(emb.embedding.weight.grad, want)
 
 
 def test_entmax_matches_reference_vectors():

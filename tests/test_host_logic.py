@@ -73,10 +73,11 @@ def test_cpu_tensors_are_rejected_loudly():
         entmax_bisect(torch.zeros(2, 5))
 
 
-def test_training_mode_is_refused_explicitly():
+def test_training_mode_also_refuses_cpu_tensors():
+    from armnet_hip import native
     meta, sd, ids, vals, _ = load("g7_odd_1h_f13_e12_h7_a1.5")
     m = build_model(meta, sd).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
         m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
 
 
