@@ -192,3 +192,19 @@ def test_row_sharded_path_is_bit_equal_to_replicated(name):
         m.shard_embedding()
         got = m.arm_block(idt, vt.clone())
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["g2_criteo_1h_a1.7_stress", "g7_odd_1h_f13_e12_h7_a1.5"])
+def test_from_rows_entry_point_is_bit_equal(name):
+    """armnet_fused_fwd_from_rows_f32 (pre-gathered unscaled rows) == the gather-fused entry point."""
+    from armnet_hip.block import arm_block_forward
+    meta, sd, ids, vals, ref = load(name)
+    m = build_model(meta, sd, DEV)
+    idt = torch.from_numpy(ids).to(DEV)
+    with torch.no_grad():
+        want = m.arm_block(idt, torch.from_numpy(vals.copy()).to(DEV))
+        qf, sc, sh = m._folded.q_fold, m._folded.bn_scale, m._folded.bn_shift
+        rows = m.embedding.embedding.weight[idt].contiguous()                    # [B,F,E] unscaled
+        got = arm_block_forward(None, torch.from_numpy(vals.copy()).to(DEV), None, qf, m.attn_layer.values, sc, sh,
+                                m.alpha, rows=rows)
+    assert torch.equal(got, want)

@@ -87,3 +87,32 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
         native.load()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout not present")
+def test_reference_model_factory_builds_hip_modules_when_this_package_is_first_on_path():
+    """Drop-in plumbing (BASELINE.json configs[0]): with arm-net_amd ahead of the reference on sys.path the
+    reference's own create_model (models/model_utils.py:27-49) constructs OUR ARMNetModel classes.  Runs only
+    where the reference is mounted; nothing of it is imported on the GPU box."""
+    import subprocess
+    import sys as _sys
+    code = r'''
+import sys, types, logging
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, "/root/reference"]
+from models.model_utils import create_model
+import armnet_hip.modules as hm
+log = logging.getLogger("t")
+for name in ("armnet", "armnet_1h"):
+    a = types.SimpleNamespace(model=name, nfield=10, nfeat=5382, nemb=10, nattn_head=2, alpha=1.7, h=10, mlp_nlayer=2,
+                              mlp_nhid=32, dropout=0.0, ensemble=True, dnn_nlayer=2, dnn_nhid=32, k=3)
+    m = create_model(a, log)
+    assert isinstance(m, hm.ArmNetBase), type(m)
+    assert type(m.embedding).__name__ == "HipEmbedding"
+# a baseline model of the reference still builds (its layers come from the reference through our layers.py)
+a = types.SimpleNamespace(model="dfm", nfield=10, nfeat=100, nemb=4, mlp_nlayer=1, mlp_nhid=8, dropout=0.0)
+assert create_model(a, log) is not None
+print("OK")
+''' % os.path.join(ROOT, "arm-net_amd")
+    out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
