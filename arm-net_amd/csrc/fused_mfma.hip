@@ -387,6 +387,9 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             } else {
                 // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
                 // they converge.  When the loop ends every row's S was evaluated at its final threshold.
+                // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
+                // at the final threshold), which saves the two transcendentals per element of a final pass
+                f32x2 pkeep[MODE == SOLVE_NEWTON ? SPW * NP : 1];
                 for (int it = 0; it < kNewtonMaxIter; ++it) {
                     wave_lds_fence();
 #pragma unroll
@@ -409,6 +412,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                                 u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
                                 sv = u * t;
                                 dv = u;
+                                pkeep[s * NP + jp] = sv;
                             }
                             S2 = jp == 0 ? sv : S2 + sv;
                             D2 = jp == 0 ? dv : D2 + dv;
@@ -440,13 +444,13 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                     const f32x2 tk = {tau[s], tau[s]};
 #pragma unroll
                     for (int jp = 0; jp < NP; ++jp) {
-                        const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
                         f32x2 p;
-                        if constexpr (MODE == SOLVE_MICHELOT) p = t;
-                        else if constexpr (MODE == SOLVE_NEWTON15) p = t * t;
-                        else {
-                            p[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));
-                            p[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
+                        if constexpr (MODE == SOLVE_NEWTON) {
+                            p = pkeep[s * NP + jp];
+                        } else {
+                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                            if constexpr (MODE == SOLVE_MICHELOT) p = t;
+                            else p = t * t;
                         }
                         XP_SET(s, jp, p * VV(jp));
                     }
@@ -543,7 +547,8 @@ template <int E, int NQ, int MODE, int SRC>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
     // E = 64: one sample per group (48-row padded tile) keeps LDS at 14 KB/wave and the row prefetch at 48 VGPRs
     constexpr int SPW = (E >= 64) ? 1 : 4 / cgcd(NQ, 4);
-    constexpr int WPS = (E >= 64) ? 3 : ARMNET_WPS;
+    // generic-alpha Newton keeps two transcendental temporaries per pair alive: 3 waves/SIMD avoids its spills
+    constexpr int WPS = (E >= 64 || MODE == SOLVE_NEWTON) ? 3 : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = a.O / 16;
     const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +
