@@ -208,3 +208,23 @@ def test_from_rows_entry_point_is_bit_equal(name):
         got = arm_block_forward(None, torch.from_numpy(vals.copy()).to(DEV), None, qf, m.attn_layer.values, sc, sh,
                                 m.alpha, rows=rows)
     assert torch.equal(got, want)
+
+
+def test_nan_value_poisons_only_its_own_sample():
+    """clamp_(NaN) stays NaN in the reference (armnet_1h.py:81) and makes that sample's neurons NaN;
+    the other samples of the same wave-group are untouched (compared with the oracle)."""
+    meta, sd, ids, vals, _ = load("g2_criteo_1h_a2.0_stress")
+    m = build_model(meta, sd, DEV)
+    g = torch.Generator().manual_seed(9)
+    B = 64
+    idt = torch.randint(0, meta["ctor"]["nfeat"], (B, 39), generator=g)
+    vt = torch.rand(B, 39, generator=g)
+    vt[5, 7] = float("nan")
+    with torch.no_grad():
+        got = m.arm_block(idt.to(DEV), vt.clone().to(DEV)).cpu().numpy()
+    v = vt.numpy().copy()
+    want = orc.arm_block("1h", idt.numpy(), v, sd, 2.0)
+    assert np.isnan(got[5]).all() and np.isnan(want[5]).all()
+    ok = np.ones(B, bool); ok[5] = False
+    assert np.isfinite(got[ok]).all()
+    assert _rel_err(got[ok], want[ok]) <= TOL
