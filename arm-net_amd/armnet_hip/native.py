@@ -25,7 +25,7 @@ EXPORTS = (
     "armnet_abi_version", "armnet_strerror", "armnet_last_hip_error", "armnet_fold_params_f32",
     "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
     "armnet_clamp_vals_f32", "armnet_entmax_f32", "armnet_shard_route_ws_bytes", "armnet_shard_route_ids",
-    "armnet_fused_bwd_f32",
+    "armnet_fused_bwd_f32", "armnet_shard_route_unique_ws_bytes", "armnet_shard_route_unique_ids",
 )
 
 _lib = None
@@ -58,6 +58,7 @@ def load():
             raise ArmnetNativeError(f"{LIB_PATH} does not export {name}")
     lib.armnet_strerror.restype = ctypes.c_char_p
     lib.armnet_shard_route_ws_bytes.restype = ctypes.c_int64
+    lib.armnet_shard_route_unique_ws_bytes.restype = ctypes.c_int64
     lib.armnet_last_hip_error.restype = ctypes.c_char_p
     if lib.armnet_abi_version() != ABI_VERSION:
         raise ArmnetNativeError(f"ABI version mismatch: library {lib.armnet_abi_version()} != binding {ABI_VERSION}")
@@ -182,3 +183,20 @@ def fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values
                                       ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
                                       ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
                                       _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+
+
+def shard_route_unique_ws_bytes(R, nfeat):
+    return int(load().armnet_shard_route_unique_ws_bytes(int(R), ctypes.c_int64(nfeat)))
+
+
+def shard_route_unique_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_status=None):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    for name, t in (("counts", counts), ("send_local", send_local), ("perm", perm)):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise ArmnetNativeError(f"{name}: expected a contiguous int32 tensor on the HIP device")
+    check(load().armnet_shard_route_unique_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R),
+                                               ctypes.c_int64(nfeat), _ptr(counts), _ptr(send_local), _ptr(perm),
+                                               ctypes.c_void_p(0), _ptr(workspace),
+                                               ctypes.c_int64(workspace.numel() * workspace.element_size()),
+                                               _ptr(id_status), _stream()))

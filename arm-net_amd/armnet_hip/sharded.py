@@ -7,7 +7,7 @@ balances skewed ids).  One lookup of a rank's ``ids [B, F]``:
     exchange   all_gather of the R counts  ->  every rank knows the R x R split matrix (tiny)
     exchange   all_to_all_single of int32 local row indices                             (RCCL over xGMI)
     gather     armnet_gather_scale_f32(vals=NULL): owner reads its rows                 (HIP, HBM-bound)
-    exchange   all_to_all_single of the rows (E*4 bytes per id)                         (RCCL over xGMI)
+    exchange   all_to_all_single of the rows (E*4 bytes per DISTINCT id with de-dup)    (RCCL over xGMI)
     consume    armnet_fused_fwd_f32 with table = received rows, ids = perm (int32)      (no un-permute pass)
 
 The arithmetic of the fused block is untouched: the sharded result is bit-equal to the single-GPU one.
@@ -23,14 +23,24 @@ from . import native
 class HipShardOps:
     """Device kernels of the sharded lookup (C ABI).  CPU tensors are rejected by the binding."""
 
-    def route(self, ids_flat, R, nfeat):
+    def __init__(self):
+        self._ws = None          # workspace of the de-duplicating route, reused across steps
+
+    def route(self, ids_flat, R, nfeat, dedup=False):
+        """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once."""
         n = ids_flat.numel()
         dev = ids_flat.device
         counts = torch.empty(R, device=dev, dtype=torch.int32)
         send_local = torch.empty(n, device=dev, dtype=torch.int32)
         perm = torch.empty(n, device=dev, dtype=torch.int32)
-        ws = torch.empty(max(native.shard_route_ws_bytes(n, R), 4), device=dev, dtype=torch.uint8)
-        native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws)
+        if dedup:
+            need = native.shard_route_unique_ws_bytes(R, nfeat)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            native.shard_route_unique_ids(n, ids_flat, R, nfeat, counts, send_local, perm, self._ws)
+        else:
+            ws = torch.empty(max(native.shard_route_ws_bytes(n, R), 4), device=dev, dtype=torch.uint8)
+            native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws)
         return counts, send_local, perm
 
     def gather(self, local_idx, table_local):
@@ -48,7 +58,8 @@ def shard_rows(full_table, rank, world):
 class RowShardedTable:
     """One rank's shard of the embedding table + the lookup protocol above."""
 
-    def __init__(self, table_local, nfeat, group=None, ops=None):
+    def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto"):
+        self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
         self.table_local = table_local
         self.nfeat = int(nfeat)
         self.group = group
@@ -64,10 +75,12 @@ class RowShardedTable:
         R = self.world
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
-        counts, send_local, perm = self.ops.route(flat, R, self.nfeat)
+        dedup = (8 * n >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
+        counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
         E = self.table_local.shape[1]
         if R == 1 and not dist.is_initialized():
-            return self.ops.gather(send_local, self.table_local), perm
+            n_send = int(counts.sum().item()) if dedup else n
+            return self.ops.gather(send_local[:n_send], self.table_local), perm
         # split matrix: row q = what rank q sends to each owner
         allc = torch.empty(R * R, device=counts.device, dtype=torch.int32)
         dist.all_gather_into_tensor(allc, counts, group=self.group)
@@ -75,9 +88,10 @@ class RowShardedTable:
         send_counts = m[self.rank].tolist()
         recv_counts = m[:, self.rank].tolist()
         recv_idx = torch.empty(sum(recv_counts), device=flat.device, dtype=torch.int32)
-        dist.all_to_all_single(recv_idx, send_local, recv_counts, send_counts, group=self.group)
+        n_send = sum(send_counts)                      # == n without de-duplication
+        dist.all_to_all_single(recv_idx, send_local[:n_send], recv_counts, send_counts, group=self.group)
         rows_out = self.ops.gather(recv_idx, self.table_local)
-        rows_in = torch.empty(n, E, device=flat.device, dtype=torch.float32)
+        rows_in = torch.empty(n_send, E, device=flat.device, dtype=torch.float32)
         dist.all_to_all_single(rows_in, rows_out, send_counts, recv_counts, group=self.group)
         return rows_in, perm
 

@@ -241,10 +241,11 @@ def main():
             line["row_sharded"] = {
                 "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
                 "ms_per_step": sharded_ms / a.steps,
-                "note": f"same block with the table row-sharded (row i on rank i mod {world}): HIP counting-sort "
-                        f"routing, all_to_all_single of int32 row indices, owner-side gather, all_to_all_single of "
-                        f"{a.nemb * 4}-byte rows ({(world - 1) / world:.0%} of {a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB "
-                        f"per rank per step cross xGMI), fused kernel over (rows, perm)"}
+                "note": f"same block with the table row-sharded (row i on rank i mod {world}): HIP routing with per-rank "
+                        f"id de-duplication (direct-address mark + scan), all_to_all_single of int32 row indices, "
+                        f"owner-side gather, all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
+                        f"{a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB per rank per step, {(world - 1) / world:.0%} of it "
+                        f"across xGMI), fused kernel over (rows, perm)"}
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             line["cpu_baseline"] = cpu_baseline(a, model, ids_cpu, vals_cpu)
         print(json.dumps(line), flush=True)

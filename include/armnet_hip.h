@@ -155,6 +155,17 @@ int armnet_shard_route_ids(int64_t n, const void* ids, int id_type, int R, int64
                            int32_t* counts, int32_t* send_local, int32_t* perm,
                            void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
 
+/*
+ * The same routing with per-rank de-duplication: every distinct id of the batch is sent (and its row
+ * received) once.  send_local then has n_unique = sum(counts) entries (capacity n), perm[i] is the slot of
+ * id i's row among them, *n_unique (optional device int32) receives the total.  Direct-address marking +
+ * one exclusive scan over R * ceil(nfeat / R) flags: pays when the batch is not much smaller than the table.
+ */
+int64_t armnet_shard_route_unique_ws_bytes(int R, int64_t nfeat);
+int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                                  int32_t* counts, int32_t* send_local, int32_t* perm, int32_t* n_unique,
+                                  void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

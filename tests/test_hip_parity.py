@@ -177,6 +177,22 @@ def test_shard_route_kernel_contract(R, dtype):
     np.testing.assert_array_equal(perm, perm2)                    # deterministic
 
 
+@pytest.mark.parametrize("R", [1, 2, 8])
+def test_shard_route_unique_kernel_contract(R):
+    """armnet_shard_route_unique_ids: every distinct id once, grouped by owner, rows[perm] == table[ids]."""
+    from armnet_hip.sharded import HipShardOps
+    nfeat, n = 5003, 39 * 811                                     # ~6 lookups per row: heavy duplication
+    ids = torch.randint(0, nfeat, (n,), generator=torch.Generator().manual_seed(R))
+    counts, send_local, perm = (t.cpu().numpy() for t in HipShardOps().route(ids.to(DEV), R, nfeat, dedup=True))
+    idn = ids.numpy()
+    nu = int(counts.sum())
+    assert nu == np.unique(idn).size
+    owner_of_slot = np.repeat(np.arange(R), counts)
+    np.testing.assert_array_equal(owner_of_slot[perm], idn % R)
+    np.testing.assert_array_equal(send_local[:nu][perm], idn // R)
+    assert np.unique(np.stack([owner_of_slot, send_local[:nu]]), axis=1).shape[1] == nu      # no duplicates sent
+
+
 @pytest.mark.parametrize("name", ["g2_criteo_1h_a2.0_stress", "g4_criteo_1h_e64_a1.7_stress", "g3_criteo_mh4_a2.0_stress"])
 def test_row_sharded_path_is_bit_equal_to_replicated(name):
     """world_size 1 exercises route -> gather -> fused kernel over (rows, perm): sharding only moves rows,
@@ -190,8 +206,10 @@ def test_row_sharded_path_is_bit_equal_to_replicated(name):
     with torch.no_grad():
         want = m.arm_block(idt, vt.clone())
         m.shard_embedding()
-        got = m.arm_block(idt, vt.clone())
-    assert torch.equal(got, want)
+        for dedup in (False, True):
+            m._shard.dedup = dedup
+            got = m.arm_block(idt, vt.clone())
+            assert torch.equal(got, want), f"dedup={dedup}"
 
 
 @pytest.mark.parametrize("name", ["g2_criteo_1h_a1.7_stress", "g7_odd_1h_f13_e12_h7_a1.5"])

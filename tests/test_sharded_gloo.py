@@ -17,8 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class NumpyShardOps:
     """Test double with the same contract as HipShardOps (armnet_shard_route_ids / gather)."""
 
-    def route(self, ids_flat, R, nfeat):
+    def route(self, ids_flat, R, nfeat, dedup=False):
         ids = ids_flat.numpy().astype(np.int64)
+        if dedup:       # every distinct id once, grouped by owner, sorted by local row index
+            L = (nfeat + R - 1) // R
+            pos = (ids % R) * L + ids // R
+            upos, inv = np.unique(pos, return_inverse=True)
+            counts = np.bincount(upos // L, minlength=R).astype(np.int32)
+            send_local = np.zeros(ids.size, np.int32)
+            send_local[: upos.size] = (upos % L).astype(np.int32)
+            return torch.from_numpy(counts), torch.from_numpy(send_local), torch.from_numpy(inv.astype(np.int32))
         owner = ids % R
         order = np.argsort(owner, kind="stable")
         perm = np.empty(ids.size, np.int32)
@@ -31,7 +39,7 @@ class NumpyShardOps:
         return table_local[local_idx.long()].contiguous()
 
 
-def _worker(rank, world, port, nfeat, E, B, F, q):
+def _worker(rank, world, port, nfeat, E, B, F, q, dedup=False):
     sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +52,7 @@ def _worker(rank, world, port, nfeat, E, B, F, q):
         ids = torch.randint(0, nfeat, (B, F), generator=g2)
         ids[0, :3] = torch.tensor([0, nfeat - 1, 1])                     # boundary rows, both owners
         ids[1, :] = ids[1, 0]                                            # duplicates in one sample
-        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps())
+        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=dedup)
         rows, perm = shard.lookup(ids)
         got = rows[perm.long()].view(B, F, E)
         ok = bool(torch.equal(got, table[ids]))
@@ -53,12 +61,12 @@ def _worker(rank, world, port, nfeat, E, B, F, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_lookup_protocol_gloo(world):
+@pytest.mark.parametrize("world,dedup", [(2, False), (3, False), (2, True)])
+def test_sharded_lookup_protocol_gloo(world, dedup):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 1001, 8, 37, 5, q)) for r in range(world)]
+    port = 29500 + os.getpid() % 2000 + world + (10 if dedup else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 1001, 8, 37, 5, q, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -66,7 +74,7 @@ def test_sharded_lookup_protocol_gloo(world):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert [r[1] for r in res] == [True] * world, res
-    assert all(r[2] == 37 * 5 for r in res)
+    assert all((r[2] == 37 * 5) if not dedup else (r[2] <= 37 * 5) for r in res)
 
 
 def test_numpy_double_matches_route_contract():
