@@ -119,7 +119,8 @@ def cpu_baseline(a, model, ids_cpu, vals_cpu):
     """The CPU oracle (oracle/armnet_oracle.c, kind "port") on this host's cores, bounded sample."""
     from oracle import armnet_oracle as orc
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    threads = orc.max_threads()
+    threads = orc.effective_cpus()              # affinity and cgroup CPU quota, not just the core count
+    orc.set_threads(threads)
     variant = "1h" if a.nhead == 1 else "mh"
     n = min(a.batch, 65536)
     ids = ids_cpu[:n].numpy()
@@ -133,9 +134,18 @@ def cpu_baseline(a, model, ids_cpu, vals_cpu):
         passes += 1
         if passes == 1 and t_used > a.cpu_seconds / 2:
             break
+    # one-thread line: a 2048-sample slice through the same entry point
+    orc.set_threads(1)
+    n1 = min(n, 2048)
+    v = vals_cpu[:n1].numpy().copy()
+    t0 = time.perf_counter()
+    orc.arm_block(variant, ids[:n1], v, sd, a.alpha)
+    t1 = time.perf_counter() - t0
+    orc.set_threads(threads)
     return {"value": done / t_used, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"{passes} pass(es) of the first {n} samples of the same batch through "
-                      f"oracle_arm_block (50-step bisection, OpenMP, {threads} threads)"}
+                      f"oracle_arm_block (50-step bisection, OpenMP, {threads} threads)",
+            "one_thread": {"value": n1 / t1, "unit": "samples/s", "sample": f"{n1} samples, 1 thread"}}
 
 
 def pmc_traffic(a):

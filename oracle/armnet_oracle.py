@@ -56,6 +56,18 @@ def max_threads():
     return int(lib().armnet_oracle_max_threads())
 
 
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup v2 quota, OpenMP default)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, max_threads()))
+
+
 def clamp_vals(vals):
     assert vals.dtype == np.float32 and vals.flags["C_CONTIGUOUS"]
     lib().oracle_clamp_vals(_fp(vals), ctypes.c_int64(vals.size))
