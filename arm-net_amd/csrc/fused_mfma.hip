@@ -120,24 +120,6 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     float* p_vv = p_bq + NT * EB * 64 * 4;                 // [NT][NP][64] f32x2
     float* p_bn = p_vv + NT * NP * 64 * 2;                 // [NT][16] f32x2 {scale, shift}
 
-    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
-        const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
-        const int o = 16 * nt + (l & 15);
-        *reinterpret_cast<f32x4*>(p_bq + i * 4) =
-            *reinterpret_cast<const f32x4*>(a.q_fold + (size_t)o * E + 16 * kb + 4 * (l >> 4));
-    }
-    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
-        const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
-        const int o = 16 * nt + (l & 15);
-        const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
-        f32x2 v;
-        v[0] = f0 < F ? a.values[(size_t)o * F + f0] : 0.f;
-        v[1] = f1 < F ? a.values[(size_t)o * F + f1] : 0.f;
-        *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
-    }
-    for (int i = threadIdx.x; i < NT * 16; i += 256)
-        *reinterpret_cast<f32x2*>(p_bn + i * 2) = f32x2{a.bn_scale[i], a.bn_shift[i]};
-    __syncthreads();
 
     // all group bookkeeping is 32-bit and wave-uniform (SALU): launcher guarantees B*F*8 < 2^32
     const int Bi = (int)a.B;
@@ -145,7 +127,6 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const int ngroups = (Bi + SPW - 1) / SPW;
     const int nwaves = (int)gridDim.x * 4;
     int grp = (int)blockIdx.x * 4 + wave;
-    if (grp >= ngroups) return;
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
@@ -236,7 +217,26 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         }
     };
 
-    fetch_raw(grp);
+    if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
+    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+        const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
+        const int o = 16 * nt + (l & 15);
+        *reinterpret_cast<f32x4*>(p_bq + i * 4) =
+            *reinterpret_cast<const f32x4*>(a.q_fold + (size_t)o * E + 16 * kb + 4 * (l >> 4));
+    }
+    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
+        const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
+        const int o = 16 * nt + (l & 15);
+        const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
+        f32x2 v;
+        v[0] = f0 < F ? a.values[(size_t)o * F + f0] : 0.f;
+        v[1] = f1 < F ? a.values[(size_t)o * F + f1] : 0.f;
+        *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
+    }
+    for (int i = threadIdx.x; i < NT * 16; i += 256)
+        *reinterpret_cast<f32x2*>(p_bn + i * 2) = f32x2{a.bn_scale[i], a.bn_shift[i]};
+    __syncthreads();
+    if (grp >= ngroups) return;
     issue_rows_vals(grp);
     fetch_raw(grp + nwaves);
 #ifdef ARMNET_PHASE_TIMING
