@@ -192,6 +192,10 @@ class ArmNetBase(nn.Module):
         self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group)
         return self
 
+    def make_graphed(self, ids, vals):
+        """Capture this model's inference forward for the shape of (ids, vals) in a hipGraph."""
+        return GraphedForward(self, ids, vals)
+
     def forward(self, x, vals=None):
         """x = {'id': Long[B,F], 'value': Float[B,F], ...} -> logits Float[B] (armnet_1h.py:76-98).
         Also accepts forward(ids, vals).  x['value'] is clamped to [1e-3, 1] IN PLACE."""
@@ -211,6 +215,45 @@ class ArmNetBase(nn.Module):
             y_deep = self.deep_mlp(x_deep.view(x_deep.shape[0], -1))
             y = self.ensemble_layer(torch.cat([y, y_deep], dim=1))
         return y.squeeze()
+
+
+class GraphedForward:
+    """hipGraph-captured inference of one ARM-Net module at a fixed batch shape (serving / small batches,
+    where per-call host overhead — allocation, ctypes, three launches + the MLP's GEMMs — exceeds the
+    kernels).  Inputs are copied into static device buffers, the captured graph is replayed, and the static
+    logits buffer is returned (clone it if it must outlive the next call).  The in-place clamp of
+    x['value'] is applied to the static copy and mirrored back to the caller's tensor."""
+
+    def __init__(self, model, ids, vals, warmup=3):
+        if model.training:
+            raise RuntimeError("GraphedForward captures the inference path: call model.eval() first")
+        self.model = model
+        self.ids = ids.clone()
+        self.vals = vals.clone()
+        check = model.check_ids
+        model.check_ids = False                     # no host sync inside a capture
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    model({"id": self.ids, "value": self.vals})
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = model({"id": self.ids, "value": self.vals})
+        finally:
+            model.check_ids = check
+
+    def __call__(self, x, vals=None):
+        ids, v = (x["id"], x["value"]) if vals is None else (x, vals)
+        if ids.shape != self.ids.shape or v.shape != self.vals.shape:
+            raise ValueError(f"graph was captured for batch shape {tuple(self.ids.shape)}, got {tuple(ids.shape)}")
+        self.ids.copy_(ids)
+        self.vals.copy_(v)
+        self.graph.replay()
+        v.copy_(self.vals)                          # the reference's visible clamp side effect
+        return self.out
 
 
 class _MLP(nn.Module):

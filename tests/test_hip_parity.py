@@ -246,3 +246,21 @@ def test_nan_value_poisons_only_its_own_sample():
     ok = np.ones(B, bool); ok[5] = False
     assert np.isfinite(got[ok]).all()
     assert _rel_err(got[ok], want[ok]) <= TOL
+
+
+def test_hipgraph_captured_forward_matches_eager():
+    """GraphedForward: static buffers + hipGraph replay give the eager logits and the clamp side effect."""
+    meta, sd, ids, vals, ref = load("g2_criteo_1h_a2.0_stress_mlp256")
+    m = build_model(meta, sd, DEV)
+    idt = torch.from_numpy(ids).to(DEV)
+    g = m.make_graphed(idt, torch.from_numpy(vals.copy()).to(DEV))
+    for shift in (0, 1):                                   # replay twice with different inputs
+        idx = torch.roll(idt, shift, 0)
+        v = torch.roll(torch.from_numpy(vals.copy()).to(DEV), shift, 0)
+        v2 = v.clone()
+        with torch.no_grad():
+            want = m({"id": idx, "value": v2})
+        got = g({"id": idx, "value": v})
+        assert torch.equal(got, want)
+        assert torch.equal(v, v2)
+    assert _rel_err(g({"id": idt, "value": torch.from_numpy(vals.copy()).to(DEV)}).cpu().numpy(), ref["logits"]) <= TOL
