@@ -264,3 +264,25 @@ def test_hipgraph_captured_forward_matches_eager():
         assert torch.equal(got, want)
         assert torch.equal(v, v2)
     assert _rel_err(g({"id": idt, "value": torch.from_numpy(vals.copy()).to(DEV)}).cpu().numpy(), ref["logits"]) <= TOL
+
+
+def test_device_resident_loader_feeds_the_model():
+    """data_loader.DeviceLoader: the split lives in HBM, batches are slices; a train.py-style eval loop over it."""
+    import os
+    from data_loader import DeviceLoader, LibsvmDataset
+    from golden_util import GOLDEN
+    ds = LibsvmDataset(os.path.join(GOLDEN, "libsvm_small.libsvm"), 10)
+    meta, sd, _, _, _ = load("g1_frappe_1h_a1.7_stress")
+    m = build_model(meta, sd, DEV)
+    seen, outs = 0, []
+    for batch in DeviceLoader(ds, batch_size=32, device=DEV):
+        assert batch["id"].is_cuda and batch["value"].is_cuda
+        with torch.no_grad():
+            outs.append(m(batch))
+        seen += batch["y"].numel()
+    assert seen == ds.nsamples
+    with torch.no_grad():
+        want = m({"id": ds.feat_id[: ds.nsamples].to(DEV), "value": ds.feat_value[: ds.nsamples].clone().to(DEV)})
+    assert torch.equal(torch.cat(outs), want)
+    shuffled = [b["y"].numel() for b in DeviceLoader(ds, batch_size=48, shuffle=True, device=DEV, drop_last=True)]
+    assert shuffled == [48, 48]
