@@ -283,6 +283,7 @@ def test_device_resident_loader_feeds_the_model():
     assert seen == ds.nsamples
     with torch.no_grad():
         want = m({"id": ds.feat_id[: ds.nsamples].to(DEV), "value": ds.feat_value[: ds.nsamples].clone().to(DEV)})
-    assert torch.equal(torch.cat(outs), want)
+    # the MLP's hipBLASLt GEMMs pick batch-size-dependent kernels: equal to rounding, not bit for bit
+    torch.testing.assert_close(torch.cat(outs), want, rtol=1e-5, atol=1e-6)
     shuffled = [b["y"].numel() for b in DeviceLoader(ds, batch_size=48, shuffle=True, device=DEV, drop_last=True)]
     assert shuffled == [48, 48]
