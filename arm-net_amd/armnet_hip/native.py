@@ -26,6 +26,7 @@ EXPORTS = (
     "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
     "armnet_clamp_vals_f32", "armnet_entmax_f32", "armnet_shard_route_ws_bytes", "armnet_shard_route_ids",
     "armnet_fused_bwd_f32", "armnet_shard_route_unique_ws_bytes", "armnet_shard_route_unique_ids",
+    "armnet_fused_kernel_kind",
 )
 
 _lib = None
@@ -110,6 +111,15 @@ def fold_params(variant, K, H, E, D, bilinear_w, query, bn_w, bn_b, bn_mean, bn_
     check(load().armnet_fold_params_f32(variant, K, H, E, D, _ptr(bilinear_w), _ptr(query), _ptr(bn_w),
                                         _ptr(bn_b), _ptr(bn_mean), _ptr(bn_var), ctypes.c_float(eps),
                                         _ptr(q_fold), _ptr(bn_scale), _ptr(bn_shift), _stream()))
+
+
+def fused_kernel_kind(F, E, O, alpha, n_iter=50, flags=0):
+    """1 = the matrix-core kernel serves this shape, 0 = the generic kernel (host-only query)"""
+    rc = load().armnet_fused_kernel_kind(int(F), int(E), int(O), ctypes.c_float(alpha), int(n_iter),
+                                         ctypes.c_uint32(flags))
+    if rc < 0:
+        check(rc)
+    return rc
 
 
 def fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, bn_scale, bn_shift, out,

@@ -48,6 +48,12 @@ int armnet_fold_params_f32(int variant, int K, int H, int E, int D, const float*
                               bn_running_var, bn_eps, q_fold, bn_scale, bn_shift, (hipStream_t)stream);
 }
 
+int armnet_fused_kernel_kind(int F, int E, int O, float alpha, int n_iter, uint32_t flags) {
+    if (F <= 0 || E <= 0 || O <= 0 || n_iter < 0 || !(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
+    const SparseMapCfg cfg = make_sparse_cfg(alpha, n_iter, F, 1, flags);
+    return (!(flags & ARMNET_F_FORCE_GENERIC) && cfg.mode != SOLVE_BISECT && fused_mfma_supports(F, E, O)) ? 1 : 0;
+}
+
 static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (a.B < 0 || a.F <= 0 || a.E <= 0 || a.O <= 0 || n_iter < 0) return ARMNET_ERR_BAD_ARG;
     if (!a.vals || !a.q_fold || !a.values || !a.bn_scale || !a.bn_shift || !a.out) return ARMNET_ERR_BAD_ARG;

@@ -230,6 +230,7 @@ struct FusedArgs {
     const float* bn_scale;
     const float* bn_shift;
     float* out;           // [B,O,E]
+    int O_out;            // neurons per sample in `out` (0 = O): the MFMA path covers > 256 neurons in slices
     int32_t* id_status;
     uint32_t flags;
     SparseMapCfg cfg;

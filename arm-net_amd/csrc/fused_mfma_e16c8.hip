@@ -1,0 +1,18 @@
+// fused_mfma_e16c8.hip — instantiations of the fused MFMA kernel for nemb padded to 16, 8-byte staging chunks.
+#include "fused_mfma_kernel.h"
+
+namespace armnet {
+
+int launch_mfma_e16_c8(const FusedArgs& a, int nq, hipStream_t st) {
+    switch (nq) {
+        case 2: return launch_src<16, 2, 8, true>(a, st);
+        case 4: return launch_src<16, 4, 8, true>(a, st);
+        case 6: return launch_src<16, 6, 8, true>(a, st);
+        case 8: return launch_src<16, 8, 8, true>(a, st);
+        case 10: return launch_src<16, 10, 8, true>(a, st);
+        case 12: return launch_src<16, 12, 8, true>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace armnet

@@ -1,0 +1,17 @@
+// fused_mfma_e64c16.hip — instantiations of the fused MFMA kernel for nemb padded to 64, 16-byte staging chunks.
+#include "fused_mfma_kernel.h"
+
+namespace armnet {
+
+int launch_mfma_e64_c16(const FusedArgs& a, int nq, hipStream_t st) {
+    switch (nq) {
+        case 4: return launch_src<64, 4, 16, true>(a, st);
+        case 6: return launch_src<64, 6, 16, true>(a, st);
+        case 8: return launch_src<64, 8, 16, true>(a, st);
+        case 10: return launch_src<64, 10, 16, true>(a, st);
+        case 12: return launch_src<64, 12, 16, true>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace armnet

@@ -1,0 +1,666 @@
+// fused_mfma_kernel.h — the fused ARM block on the CDNA4 matrix cores (gfx950), fp32 end to end.
+// Template + launcher; instantiated per (padded embedding width, chunk size) family in fused_mfma_*.hip.
+//
+// Measured facts this kernel is built around (tools/ubench/valu_rate.hip, profiles/):
+//   * v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and its cycles ADD to the VALU cycles of
+//     the same SIMD (no overlap) -> the budget per sample is 40 MFMAs * 32 cycles + every other instruction;
+//   * one wave issues a VALU op at most every ~8 cycles -> >= 3-4 waves/SIMD (<= 128 VGPRs) are needed;
+//   * the LDS pipe is otherwise idle -> cross-lane reductions and parameter fetches go through LDS.
+//
+// One WAVE owns a group of SPW samples at a time and never talks to another wave (wave-private
+// LDS tile, no block barrier after the prologue).  Per group:
+//
+//   stage     coalesced chunk loads (16 B, or 8 B when nemb % 4 != 0) of the F embedding rows of each sample
+//             (adjacent lanes share a row), scaled by clamp(value), written to the wave's LDS tile whose rows
+//             are zero-padded to E = 16/32/64 floats.  Rows of the NEXT group are already in flight
+//             (registers) and the raw ids of the group after that are being fetched.
+//   per 16-neuron pass nt:
+//   MFMA #1   gates  G[(s,f), o] = X[(s,f), :] . q_fold[o, :]   (v_mfma_f32_16x16x4_f32, exact fp32).
+//             Tile rows are ordered so that accumulator register r of tile t is "quarter-step"
+//             q = 4t + r = s*NQ + j of ONE sample (NQ = ceil(F/4) rounded up to even): lane
+//             (c = l&15, g = l>>4) holds, for neuron o = 16*nt + c, the gates of fields f = 4j + g.
+//   sparse    entmax / softmax over the fields of each (sample, neuron) row, in registers, two
+//   map       elements per instruction: t = clamp01(x - tau) is ONE v_pk_add_f32 with the neg and
+//             clamp modifiers (x - tau <= 1 always holds because tau >= max - 1).  A row is spread
+//             over the 4 lane groups g: partial sums meet through a 1 KiB LDS scratch.
+//             alpha = 2: Michelot (= Newton from the left, finite), alpha = 1.5 / generic: Newton.
+//   MFMA #2   Z^T[e, o] = sum_f X[f, e] * W[o, f]:  the C layout of MFMA #1 IS the B-operand layout
+//             of MFMA #2 (k = lane group g <-> field 4j+g): the weights never move.
+//   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte
+//             store per lane when nemb is a multiple of 16 (element stores otherwise).
+//
+// Shapes: nemb even and <= 64, nfield <= 48, nhead*nhid <= 256 (neurons padded to 16 per pass).
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "armnet_common.h"
+
+namespace armnet {
+
+// 16 zero bytes in device memory: what a staging lane reads when its chunk is padding
+__device__ float kZeroRow[4] = {0.f, 0.f, 0.f, 0.f};   // not const: keeps the select with the table pointer in the global address space
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+// t = clamp01(x - tau), two elements per instruction
+__device__ __forceinline__ f32x2 pk_sub_clamp01(f32x2 x, f32x2 tau) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "v"(tau));
+    return r;
+}
+// clamp01(a * b), two elements per instruction (indicator of a > 0 when b is huge)
+__device__ __forceinline__ f32x2 pk_mul_clamp01(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of one wave is serviced in issue order; this only stops the COMPILER from moving
+    // a lane's reads across other lanes' writes.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// All-reduce of two per-lane partials over the 4 lane groups {l, l^16, l^32, l^48} through LDS:
+// lane-linear 8-byte writes (conflict-free), then every lane reads the 4 partials of its column.
+struct Red2 { f32x2 g0, g1, g2, g3; };
+__device__ __forceinline__ void red_write(float* scratch, int slot, int lane, float a, float b) {
+    *reinterpret_cast<f32x2*>(scratch + slot * 128 + lane * 2) = f32x2{a, b};
+}
+__device__ __forceinline__ Red2 red_read(const float* scratch, int slot, int c) {
+    const float* p = scratch + slot * 128 + c * 2;
+    Red2 r;
+    r.g0 = *reinterpret_cast<const f32x2*>(p);
+    r.g1 = *reinterpret_cast<const f32x2*>(p + 32);
+    r.g2 = *reinterpret_cast<const f32x2*>(p + 64);
+    r.g3 = *reinterpret_cast<const f32x2*>(p + 96);
+    return r;
+}
+
+// max without the sNaN-quieting v_max x,x,x the compiler adds around fmaxf on MFMA results
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+
+// E = nemb padded to 16/32/64; NQ = quarter-steps per sample (even); SPW samples per wave-group;
+// SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows; WPS = waves/SIMD the register budget targets;
+// CB = bytes per staging lane (16, or 8 when nemb % 4 != 0)
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int CB>
+__global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
+    constexpr int NQT = SPW * NQ;             // quarter-steps per group
+    constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
+    constexpr int ES = E + 4;                 // LDS row stride (floats)
+    constexpr int CF = CB / 4;                // floats per staging lane
+    constexpr int CH = E / CF;                // chunks per (padded) row
+    constexpr int RPI = 64 / CH;              // rows per staging instruction
+    constexpr int NI = NTILE * 16 / RPI;      // staging instructions per group
+    constexpr int EB = E / 16;                // 16-wide blocks of the embedding dim
+    constexpr int NP = NQ / 2;                // element pairs per row
+    constexpr bool FROM_ROWS = (SRC == 2);
+    constexpr int TILE_FLOATS = NTILE * 16 * ES;
+    constexpr int WAVE_FLOATS = TILE_FLOATS + 256;       // + reduction scratch (2 slots x 128 floats)
+    static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0 && NQ % 2 == 0 && SPW <= 2 &&
+                  (CB == 16 || CB == 8), "shape");
+    using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
+
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const int c = lane & 15, g = lane >> 4;
+    const int F = a.F, O = a.O, Er = a.E;     // Er: real embedding width (<= E)
+    const int O_out = a.O_out ? a.O_out : O;  // row stride of `out` in neurons (a slice of a wider block)
+    const int NT = (O + 15) / 16;             // 16-neuron passes (neurons padded)
+    float* xt = lds_all + wave * WAVE_FLOATS;
+    float* red = xt + TILE_FLOATS;
+    // block-shared, lane-ready parameters (zero-padded in e, f and o)
+    float* p_bq = lds_all + 4 * WAVE_FLOATS;               // [NT][EB][64] f32x4
+    float* p_vv = p_bq + NT * EB * 64 * 4;                 // [NT][NP][64] f32x2
+    float* p_bn = p_vv + NT * NP * 64 * 2;                 // [NT][16] f32x2 {scale, shift}
+
+    // all group bookkeeping is 32-bit and wave-uniform (SALU): launcher guarantees B*F*8 < 2^32
+    const int Bi = (int)a.B;
+    const uint32_t BF = (uint32_t)Bi * (uint32_t)F;
+    const int ngroups = (Bi + SPW - 1) / SPW;
+    const int nwaves = (int)gridDim.x * 4;
+    int grp = (int)blockIdx.x * 4 + wave;
+
+    // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
+    const int chunk = lane % CH;
+    const bool chunk_ok = (chunk + 1) * CF <= Er;        // chunk lies inside the real row
+    uint32_t off4[NI];   // 4 * (s*F + f) of the row this lane stages in instruction n (0 for a pad row)
+    bool pad[NI];        // pad row (field >= nfield, or a quarter-step past the group): zeroed after staging
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int row = n * RPI + lane / CH;
+        const int t = row >> 4, i = row & 15;
+        const int q = 4 * t + (i & 3);
+        const int s = q / NQ, j = q - s * NQ;
+        const int f = 4 * j + (i >> 2);
+        pad[n] = !(q < NQT && f < F);
+        off4[n] = (q < NQT && f < F) ? 4u * (uint32_t)(s * F + f) : 0u;
+    }
+    // this lane's last two quarter-steps may be pad fields: their gates become -inf
+    const float padneg_a = ((4 * (NQ - 1) + g) >= F) ? -INFINITY : 0.f;
+    const float padneg_b = (NQ >= 2 && (4 * (NQ - 2) + g) >= F) ? -INFINITY : 0.f;
+    const bool two_pad = F <= 4 * (NQ - 1);              // the even rounding of NQ added a whole pad quarter-step
+    const bool write_vals = (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) != 0;
+    const bool check_ids = a.id_status != nullptr;
+    // ablation switches for profiling (tools/kbench.py); never set by the product path
+    const bool dbg_no_solve = (a.flags & 0x100u) != 0;   // skip the Newton iterations
+    const bool dbg_hot_rows = (a.flags & 0x200u) != 0;   // fold ids into 1024 rows (cache-resident gather)
+    const bool dbg_no_store = (a.flags & 0x400u) != 0;   // skip the output stores
+    const bool dbg_no_mfma = (a.flags & 0x800u) != 0;    // replace the MFMAs by register copies
+    const uint32_t id_mask = dbg_hot_rows ? 1023u : 0xffffffffu;
+    const uint32_t id_max = (uint32_t)a.nfeat - 1u;
+    // lanes whose chunk lies in the zero padding of a row (nemb < E) read zeros: lane-constant base and stride
+    const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
+    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) + chunk * CB
+                                    : reinterpret_cast<const char*>(kZeroRow);
+    // pad rows are staged like any other (their lanes re-read element 0 of the group) and then overwritten with
+    // zeros, so that a non-finite embedding of one sample cannot leak into its group neighbour through 0 * NaN.
+    // Up to 7 pad fields per sample (nfield rounded up to 4*NQ) + the quarter-steps past the group.
+    constexpr int XQ = 4 * NTILE - NQT;                                  // quarter-steps past the group
+    constexpr int NZ = ((SPW * 7 + 4 * XQ) * (E / 4) + 63) / 64;         // zeroing instructions (upper bound)
+    const int npf = 4 * NQ - F;                                          // pad fields per sample
+    int zoff[NZ];                                                        // LDS float offset or -1
+#pragma unroll
+    for (int m = 0; m < NZ; ++m) {
+        const int idx = lane + 64 * m;
+        const int cc = idx % (E / 4), kk = idx / (E / 4);
+        int q, gg;
+        if (kk < SPW * npf) {
+            const int sz = kk / (npf > 0 ? npf : 1), f = F + kk - sz * npf;
+            q = sz * NQ + (f >> 2);
+            gg = f & 3;
+        } else {
+            const int x = kk - SPW * npf;
+            q = NQT + (x >> 2);
+            gg = x & 3;
+        }
+        zoff[m] = (q < 4 * NTILE) ? ((q >> 2) * 16 + 4 * gg + (q & 3)) * ES + 4 * cc : -1;
+    }
+    const bool any_pad = SPW * npf + 4 * XQ > 0;
+    const bool full_rows = (Er == E);                    // 16-byte stores possible
+    const uint32_t F4 = 4u * (uint32_t)F;
+
+    // ---- software pipeline -------------------------------------------------------------------------
+    // iteration k:  stage rows(k) -> LDS | range-check ids(k+1), issue row + value loads(k+1)
+    //               | issue RAW id loads(k+2) | compute(k).  Nothing loaded in an iteration is looked at
+    //               before the next one.  All per-group addressing is scalar base (SALU) + a per-lane
+    //               constant offset; groups past the end re-read the last group, and in a short last
+    //               group the lanes of the missing sample re-read sample 0 (results never stored).
+    RowT rows_cur[NI];
+    float val_cur[NI];
+    uint32_t raw_lo[NI], raw_hi[NI];
+
+    auto lane_off = [&](int n, bool short_grp) -> uint32_t {
+        return (short_grp && off4[n] >= F4) ? off4[n] - F4 : off4[n];
+    };
+    auto fetch_raw = [&](int gidx) {
+        if constexpr (!FROM_ROWS) {
+            const int gc = gidx < ngroups ? gidx : ngroups - 1;
+            const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
+            const bool short_grp = gc * SPW + SPW > Bi;              // wave-uniform, true at most once
+            const char* ids_g = reinterpret_cast<const char*>(a.ids) + (size_t)e0 * (SRC == 0 ? 8 : 4);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
+                if constexpr (SRC == 0) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(ids_g + (o << 1));
+                    raw_lo[n] = w.x;
+                    raw_hi[n] = w.y;
+                } else {
+                    raw_lo[n] = *reinterpret_cast<const uint32_t*>(ids_g + o);
+                    raw_hi[n] = 0u;
+                }
+            }
+        }
+    };
+    auto issue_rows_vals = [&](int gidx) {
+        const int gc = gidx < ngroups ? gidx : ngroups - 1;
+        const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
+        const bool short_grp = gc * SPW + SPW > Bi;
+        const char* vals_g = reinterpret_cast<const char*>(a.vals) + (size_t)e0 * 4;
+        if constexpr (!FROM_ROWS) {
+            if (check_ids) {                                         // wave-uniform branch
+                bool bad = false;
+#pragma unroll
+                for (int n = 0; n < NI; ++n) bad |= !pad[n] && (raw_hi[n] != 0u || raw_lo[n] > id_max);
+                if (bad && chunk == 0) atomicOr(a.id_status, 1);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
+            val_cur[n] = *reinterpret_cast<const float*>(vals_g + o);
+            const char* src;
+            if constexpr (FROM_ROWS) {
+                src = row_base + (size_t)(e0 + (o >> 2)) * row_bytes;
+            } else {
+                const uint32_t id = min(raw_lo[n], id_max) & id_mask;   // memory-safe even when unchecked
+                src = row_base + (size_t)id * row_bytes;
+            }
+            rows_cur[n] = *reinterpret_cast<const RowT*>(src);
+        }
+    };
+
+    if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
+    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+        const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
+        const int o = 16 * nt + (l & 15);
+        const int e0 = 16 * kb + 4 * (l >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (o < O)
+            for (int r = 0; r < 4; ++r)
+                if (e0 + r < Er) v[r] = a.q_fold[(size_t)o * Er + e0 + r];
+        *reinterpret_cast<f32x4*>(p_bq + i * 4) = v;
+    }
+    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
+        const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
+        const int o = 16 * nt + (l & 15);
+        const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
+        f32x2 v;
+        v[0] = (o < O && f0 < F) ? a.values[(size_t)o * F + f0] : 0.f;
+        v[1] = (o < O && f1 < F) ? a.values[(size_t)o * F + f1] : 0.f;
+        *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
+    }
+    for (int i = threadIdx.x; i < NT * 16; i += 256)
+        *reinterpret_cast<f32x2*>(p_bn + i * 2) = i < O ? f32x2{a.bn_scale[i], a.bn_shift[i]} : f32x2{0.f, 0.f};
+    __syncthreads();
+    if (grp >= ngroups) return;
+    issue_rows_vals(grp);
+    fetch_raw(grp + nwaves);
+#ifdef ARMNET_PHASE_TIMING
+    // developer build: per-phase s_memtime deltas, summed over all waves into id_status[0..7] (as uint32)
+    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#define PHASE(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ph_acc[i] += _n - ph_t; ph_t = _n; } while (0)
+#else
+#define PHASE(i) do {} while (0)
+#endif
+
+    const float am1 = a.cfg.am1;
+    const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
+    const float invF = 1.0f / (float)F;
+    const float tau_off = a.cfg.tau_hi_off;
+    const float L2E = 1.44269502162933349609375f;
+
+    for (; grp < ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        // ---- stage the current group's rows (scaled) into the wave's LDS tile -----------------------
+        wave_lds_fence();
+        bool changed = false;
+        float vcl[NI];
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            // clamp (armnet_1h.py:81; NaN stays NaN), scale (layers.py:21)
+            const float vraw = val_cur[n];
+            float v = __builtin_amdgcn_fmed3f(vraw, 1e-3f, 1.0f);
+            v = (vraw != vraw) ? vraw : v;
+            vcl[n] = v;
+            changed |= (v != vraw) && !pad[n];
+            const RowT r = rows_cur[n] * v;
+            const int row = n * RPI + lane / CH;
+            *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = r;
+        }
+        if (any_pad) {
+#pragma unroll
+            for (int m = 0; m < NZ; ++m)
+                if (zoff[m] >= 0) *reinterpret_cast<f32x4*>(xt + zoff[m]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // the reference's in-place clamp_: rare (a value outside [1e-3, 1]), so one wave-uniform test
+        if (write_vals && __builtin_amdgcn_ballot_w64(changed)) {
+            const uint32_t e0 = (uint32_t)b0 * (uint32_t)F;
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t idx = e0 + (off4[n] >> 2);
+                if (vcl[n] != val_cur[n] && chunk == 0 && !pad[n] && idx < BF) a.vals[idx] = vcl[n];
+            }
+        }
+        // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
+        issue_rows_vals(grp + nwaves);
+        fetch_raw(grp + 2 * nwaves);
+        wave_lds_fence();
+        PHASE(0);
+
+        for (int nt = 0; nt < NT; ++nt) {
+            // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
+            f32x4 c1[NTILE];
+#pragma unroll
+            for (int kb = 0; kb < EB; ++kb) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
+                f32x4 av[NTILE];
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t)
+                    av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                if (dbg_no_mfma) {
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) c1[t] = av[t] * bq;
+                    continue;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) {
+                        if (kb == 0 && kk == 0)
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
+                    }
+            }
+            PHASE(1);
+            // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
+#define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]
+#define XP_GET(s, jp) (f32x2{XG(s, 2 * (jp)), XG(s, 2 * (jp) + 1)})
+#define XP_SET(s, jp, v)              \
+    do {                              \
+        const f32x2 _v = (v);         \
+        XG(s, 2 * (jp)) = _v[0];      \
+        XG(s, 2 * (jp) + 1) = _v[1];  \
+    } while (0)
+            const float* vv_base = p_vv + (nt * NP * 64 + lane) * 2;
+#define VV(jp) (*reinterpret_cast<const f32x2*>(vv_base + (jp) * 128))
+
+            // ---- sparse map over the fields ------------------------------------------------------------
+            // On exit XG holds the UNNORMALISED weights p * values and kexp[s] = log2(e) / sum(p).
+            float kexp[SPW];
+            // row sum (for the mean start / NaN detection) and row max, partials to LDS
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                f32x2 sm2;
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) {
+                    f32x2 x = XP_GET(s, jp);
+                    if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
+                        x *= f32x2{am1, am1};               // entmax.py:42
+                        XP_SET(s, jp, x);
+                    }
+                    sm2 = jp == 0 ? x : sm2 + x;            // a pad field's gate is exactly 0
+                }
+                XG(s, NQ - 1) += padneg_a;                  // pad fields -> -inf (never in the support)
+                if (two_pad) XG(s, NQ - 2) += padneg_b;     // wave-uniform
+                float mx;
+                if constexpr (NQ == 2) {
+                    mx = vmax2(XG(s, 0), XG(s, 1));
+                } else {
+                    mx = vmax3(XG(s, 0), XG(s, 1), XG(s, 2));
+#pragma unroll
+                    for (int j = 3; j + 1 < NQ; j += 2) mx = vmax3(mx, XG(s, j), XG(s, j + 1));
+                    mx = vmax2(mx, XG(s, NQ - 1));
+                }
+                red_write(red, s & 1, lane, mx, sm2[0] + sm2[1]);
+            }
+            wave_lds_fence();
+            float tau[SPW], Ssum[SPW];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const Red2 r = red_read(red, s & 1, c);
+                const float mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
+                const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                if constexpr (MODE == SOLVE_SOFTMAX) {
+                    tau[s] = mx + (sm - sm);                // NaN / inf anywhere -> NaN row
+                } else {
+                    // tau0 = max(mx - 1, mean - d^-(alpha-1)) <= root; NaN/inf gates poison the row
+                    tau[s] = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
+                }
+                Ssum[s] = 1.0f;
+            }
+            PHASE(2);
+            if constexpr (MODE == SOLVE_SOFTMAX) {
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    float S = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const float p = __builtin_amdgcn_exp2f((XG(s, j) - tau[s]) * L2E);
+                        S += p;
+                        XG(s, j) = p * VV(j >> 1)[j & 1];
+                    }
+                    red_write(red, s & 1, lane, S, 0.f);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    const Red2 q = red_read(red, s & 1, c);
+                    Ssum[s] = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
+                }
+            } else {
+                // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
+                // they converge.  When the loop ends every row's S was evaluated at its final threshold.
+                // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
+                // at the final threshold), which saves the two transcendentals per element of a final pass
+                f32x2 pkeep[MODE == SOLVE_NEWTON ? SPW * NP : 1];
+                for (int it = 0; it < kNewtonMaxIter; ++it) {
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const f32x2 tk = {tau[s], tau[s]};
+                        f32x2 S2, D2;
+#pragma unroll
+                        for (int jp = 0; jp < NP; ++jp) {
+                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                            f32x2 sv, dv;
+                            if constexpr (MODE == SOLVE_MICHELOT) {
+                                sv = t;
+                                dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
+                            } else if constexpr (MODE == SOLVE_NEWTON15) {
+                                sv = t * t;
+                                dv = t;
+                            } else {
+                                f32x2 u;   // t^(r-1); log2(0) = -inf -> exp2(-inf) = 0 (r > 1)
+                                u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
+                                u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
+                                sv = u * t;
+                                dv = u;
+                                pkeep[s * NP + jp] = sv;
+                            }
+                            S2 = jp == 0 ? sv : S2 + sv;
+                            D2 = jp == 0 ? dv : D2 + dv;
+                        }
+                        red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
+                    }
+                    wave_lds_fence();
+                    bool any_active = false;
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const Red2 r = red_read(red, s & 1, c);
+                        const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);     // {S, Dv} in one register pair
+                        float Dv = sd[1];
+                        if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
+                        if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
+                        Ssum[s] = sd[0];
+                        const float f = sd[0] - 1.0f;
+                        const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
+                        const bool act = (f > kNewtonTol) && (tn > tau[s]) && !dbg_no_solve;
+                        tau[s] = act ? tn : tau[s];
+                        any_active |= act;
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(any_active)) break;
+                }
+                PHASE(3);
+                // unnormalised weights p * values (armnet_1h.py:34)
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    const f32x2 tk = {tau[s], tau[s]};
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        f32x2 p;
+                        if constexpr (MODE == SOLVE_NEWTON) {
+                            p = pkeep[s * NP + jp];
+                        } else {
+                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                            if constexpr (MODE == SOLVE_MICHELOT) p = t;
+                            else p = t * t;
+                        }
+                        XP_SET(s, jp, p * VV(jp));
+                    }
+                }
+            }
+            // normaliser (entmax.py:63-64) folded into the exponent scale: 1/S by rcp + one Newton step
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const float S = Ssum[s] + (tau[s] - tau[s]);        // NaN threshold -> NaN row
+                float r = __builtin_amdgcn_rcpf(S);
+                r = fmaf(fmaf(-S, r, 1.0f), r, r);
+                kexp[s] = L2E * r;
+            }
+
+            // ---- MFMA #2: Z^T[e, o] = sum_f X[f, e] * W[o, f]; sample chains interleaved -------------
+            const f32x2 bn = *reinterpret_cast<const f32x2*>(p_bn + (nt * 16 + c) * 2);
+            f32x4 c2[SPW][EB];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const int q = s * NQ + j;
+                        const int row = 16 * (q >> 2) + 4 * g + (q & 3);
+                        const float a2 = xt[row * ES + 16 * eb + c];
+                        if (dbg_no_mfma) {
+                            const float w = a2 * XG(s, j);
+                            c2[s][eb] = j == 0 ? f32x4{w, w, w, w} : c2[s][eb] + w;
+                            continue;
+                        }
+                        if (j == 0)
+                            c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), c2[s][eb], 0, 0, 0);
+                    }
+            PHASE(4);
+            // ---- epilogue: exp(z / S) = exp2(z * log2e / S) (rel. error <= ~|z| * 1.3e-7), BN affine, store
+            const bool fast_store = full_rows && 16 * nt + 16 <= O;      // wave-uniform: whole 16-byte stores
+            const bool o_ok = 16 * nt + c < O;
+            if (!dbg_no_store) {
+                const f32x2 bn0 = {bn[0], bn[0]}, bn1 = {bn[1], bn[1]};
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    if (b0 + s < Bi) {
+                        float* dst = a.out + ((size_t)(b0 + s) * O_out + 16 * nt + c) * (size_t)Er + 4 * g;
+                        const f32x2 ke = {kexp[s], kexp[s]};
+#pragma unroll
+                        for (int eb = 0; eb < EB; ++eb) {
+                            const f32x2 zlo = f32x2{c2[s][eb][0], c2[s][eb][1]} * ke;
+                            const f32x2 zhi = f32x2{c2[s][eb][2], c2[s][eb][3]} * ke;
+                            const f32x2 elo = {__builtin_amdgcn_exp2f(zlo[0]), __builtin_amdgcn_exp2f(zlo[1])};
+                            const f32x2 ehi = {__builtin_amdgcn_exp2f(zhi[0]), __builtin_amdgcn_exp2f(zhi[1])};
+                            const f32x2 vlo = __builtin_elementwise_fma(elo, bn0, bn1);
+                            const f32x2 vhi = __builtin_elementwise_fma(ehi, bn0, bn1);
+                            if (fast_store) {
+                                *reinterpret_cast<f32x4*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
+                            } else if (o_ok) {
+                                const int e = 16 * eb + 4 * g;
+                                if (e + 0 < Er) dst[16 * eb + 0] = vlo[0];
+                                if (e + 1 < Er) dst[16 * eb + 1] = vlo[1];
+                                if (e + 2 < Er) dst[16 * eb + 2] = vhi[0];
+                                if (e + 3 < Er) dst[16 * eb + 3] = vhi[1];
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                    for (int eb = 0; eb < EB; ++eb) asm volatile("" ::"v"(c2[s][eb]));
+            }
+#undef XG
+#undef XP_GET
+#undef XP_SET
+#undef VV
+            PHASE(5);
+        }
+    }
+#ifdef ARMNET_PHASE_TIMING
+    if (lane == 0 && a.id_status)
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned int*>(a.id_status) + i, (unsigned int)(ph_acc[i] >> 4));
+#endif
+}
+
+#ifndef ARMNET_WPS
+#define ARMNET_WPS 4
+#endif
+
+// SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
+// nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
+template <int E, int NQ, int MODE, int SRC, int CB>
+static int launch_one(const FusedArgs& a, hipStream_t st) {
+    constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
+    // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
+    // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
+    // generic-alpha Newton keeps two transcendental temporaries per pair alive)
+    constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
+                        : (E >= 32 || MODE == SOLVE_NEWTON || CB == 8) ? 3      // measured: nemb=32 is faster at 3
+                        : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
+                        : ARMNET_WPS;
+    constexpr int NTILE = (SPW * NQ + 3) / 4;
+    const int NT = (a.O + 15) / 16;
+    const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +
+                        (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32) * sizeof(float);
+    if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    const int64_t ngroups = (a.B + SPW - 1) / SPW;
+    const int64_t blocks = (ngroups + 3) / 4;
+    int per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > WPS) per_cu = WPS;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = 256 * (int64_t)per_cu;              // blocks the chip holds at once
+    // persistent grid-stride waves: the software pipeline's prologue is paid once per wave
+    int64_t want = blocks < resident ? blocks : resident;
+    if (const char* gm = getenv("ARMNET_GRID_MULT")) {          // developer knob: oversubscribe the grid
+        want = (int64_t)(resident * atof(gm));
+        if (want > blocks) want = blocks;
+        if (want < 1) want = 1;
+    }
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, CB>;
+    if (lds > 64 * 1024)
+        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<(int)want, 256, lds, st>>>(a);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+template <int E, int NQ, int SRC, int CB>
+static int launch_mode(const FusedArgs& a, hipStream_t st) {
+    switch (a.cfg.mode) {
+        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC, CB>(a, st);
+        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC, CB>(a, st);
+        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC, CB>(a, st);
+        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC, CB>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+// ids (int64 / int32) for every shape; the pre-gathered-rows source only where WITH_ROWS
+template <int E, int NQ, int CB, bool WITH_ROWS>
+static int launch_src(const FusedArgs& a, hipStream_t st) {
+    if (a.rows != nullptr) {
+        if constexpr (WITH_ROWS) return launch_mode<E, NQ, 2, CB>(a, st);
+        else return ARMNET_ERR_UNSUPPORTED;
+    }
+    return a.id_type == ARMNET_ID_I64 ? launch_mode<E, NQ, 0, CB>(a, st) : launch_mode<E, NQ, 1, CB>(a, st);
+}
+
+// one translation unit per family keeps the build parallel
+int launch_mfma_e16_c16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e16_c8(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e32_c16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e64_c16(const FusedArgs& a, int nq, hipStream_t st);
+
+}  // namespace armnet

@@ -286,7 +286,35 @@ def main():
     grad_case("h1_grad_1h_ens_a2.0_train", "1h", base(22, 128, 32, 2.0, 32, ensemble=True, mlp_nhid=16, deep_nhid=16),
               16, 84, True)
     entmax_cases()
+    run_sh_cases()
+
+
+def run_sh_cases():
+    """G9 - the block shapes of the reference's own run.sh (nemb stays at train.py's default 10), small tables."""
+    # run.sh:6 frappe armnet: 8 heads x 32 neurons
+    model_case("g9_frappe_mh8_h32_e10_a2.0", "mh", base(10, 400, 10, 2.0, 32, nhead=8, mlp_nhid=16), 9, 91, "stress")
+    # run.sh:7 frappe armnet+: 4 heads x 4 neurons, ensemble
+    model_case("g9_frappe_mh4_h4_e10_a1.5_ens", "mh",
+               base(10, 400, 10, 1.5, 4, nhead=4, ensemble=True, mlp_nhid=16, deep_nhid=16), 9, 92, "stress")
+    # run.sh:36 movielens armnet_1h: nfield 3
+    model_case("g9_movielens_1h_h128_e10_a2.0", "1h", base(3, 300, 10, 2.0, 128, mlp_nhid=16), 11, 93, "stress")
+    # run.sh:40 avazu armnet_1h
+    model_case("g9_avazu_1h_h128_e10_a1.5", "1h", base(22, 400, 10, 1.5, 128, mlp_nlayer=3, mlp_nhid=16), 7, 94, "stress")
+    # run.sh:15 avazu armnet+: 8 heads x 8 neurons
+    model_case("g9_avazu_mh8_h8_e10_a2.0", "mh", base(22, 400, 10, 2.0, 8, nhead=8, mlp_nhid=16), 7, 95, "fresh")
+    # run.sh:44 criteo armnet_1h
+    model_case("g9_criteo_1h_h128_e10_a2.0", "1h", base(39, 400, 10, 2.0, 128, mlp_nhid=16), 7, 96, "stress")
+    # run.sh:18 criteo armnet: 4 heads x 64 neurons
+    model_case("g9_criteo_mh4_h64_e10_a2.0", "mh", base(39, 400, 10, 2.0, 64, nhead=4, mlp_nhid=16), 5, 97, "stress")
+    # run.sh:22 diabetes armnet: 32 heads x 1 neuron;  run.sh:23 armnet+: 8 heads x 64 neurons (512 neurons)
+    model_case("g9_diabetes_mh32_h1_e10_a1.7", "mh", base(43, 369, 10, 1.7, 1, nhead=32, mlp_nlayer=1, mlp_nhid=16),
+               7, 98, "stress")
+    model_case("g9_diabetes_mh8_h64_e10_a1.5", "mh", base(43, 369, 10, 1.5, 64, nhead=8, mlp_nlayer=1, mlp_nhid=8),
+               5, 99, "stress")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others
+        run_sh_cases()
+    else:
+        main()

@@ -228,6 +228,86 @@ def test_from_rows_entry_point_is_bit_equal(name):
     assert torch.equal(got, want)
 
 
+def _random_model(variant, F, nfeat, E, alpha, H, K, seed):
+    """a product module with stressed random weights (no fixture): its own state_dict feeds the oracle"""
+    meta = {"variant": variant, "ctor": dict(nfield=F, nfeat=nfeat, nemb=E, alpha=alpha, nhid=H, d_k=E, nhead=K,
+                                             mlp_nlayer=1, mlp_nhid=8, dropout=0.0, ensemble=False, deep_nlayer=1,
+                                             deep_nhid=8)}
+    torch.manual_seed(seed)
+    m = build_model(meta)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        m.embedding.embedding.weight.copy_(torch.rand(nfeat, E, generator=g) * 1.6 - 0.8)
+        m.attn_layer.query.mul_(4.0)
+        m.attn_layer.values.copy_(torch.randn(m.attn_layer.values.shape, generator=g) * 0.4)
+        m.arm_bn.running_mean.copy_(torch.rand(K * H, generator=g) + 0.5)
+        m.arm_bn.running_var.copy_(torch.rand(K * H, generator=g) + 0.5)
+        m.arm_bn.weight.copy_(torch.rand(K * H, generator=g) + 0.5)
+        m.arm_bn.bias.copy_(torch.randn(K * H, generator=g) * 0.2)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    return meta, m.to(DEV), sd
+
+
+# (variant, nfield, nemb, nhid, nhead, alpha): every staging family of the MFMA kernel (nemb padded to 16/32/64,
+# 16- and 8-byte chunks), every quarter-step count, neuron counts that are not multiples of 16, > 256 neurons
+SHAPE_SWEEP = [
+    ("1h", 1, 2, 1, 1, 2.0), ("1h", 2, 4, 3, 1, 1.5), ("1h", 3, 10, 128, 1, 2.0), ("1h", 5, 6, 17, 1, 1.7),
+    ("1h", 8, 16, 16, 1, 2.0), ("1h", 9, 14, 33, 1, 1.0), ("mh", 12, 10, 20, 3, 2.0), ("1h", 16, 16, 48, 1, 1.5),
+    ("1h", 17, 18, 5, 1, 2.0), ("mh", 21, 20, 9, 2, 1.7), ("1h", 24, 24, 40, 1, 2.0), ("1h", 25, 28, 31, 1, 1.5),
+    ("1h", 31, 32, 64, 1, 1.0), ("mh", 33, 10, 64, 4, 2.0), ("1h", 39, 10, 128, 1, 2.0), ("1h", 40, 12, 100, 1, 1.7),
+    ("mh", 43, 10, 64, 8, 1.5), ("1h", 47, 8, 19, 1, 2.0), ("1h", 48, 16, 300, 1, 2.0), ("1h", 7, 36, 12, 1, 2.0),
+    ("1h", 13, 48, 20, 1, 1.5), ("1h", 22, 64, 32, 1, 2.0), ("mh", 30, 40, 10, 2, 1.7), ("1h", 44, 64, 24, 1, 1.0),
+    ("1h", 39, 60, 18, 1, 2.0), ("1h", 6, 64, 7, 1, 1.5),
+]
+
+
+@pytest.mark.parametrize("variant,F,E,H,K,alpha", SHAPE_SWEEP)
+def test_shape_sweep_against_oracle(variant, F, E, H, K, alpha):
+    """the fused block on shapes the fixtures do not hold, vs the CPU oracle; also the MFMA and the generic kernel
+    must agree with each other (both within TOL of the oracle), and int32 ids must be bit-equal to int64 ids"""
+    from armnet_hip import native
+    nfeat = 97
+    assert native.fused_kernel_kind(F, E, K * H, alpha) == 1     # the sweep is about the matrix-core kernel
+    meta, m, sd = _random_model(variant, F, nfeat, E, alpha, H, K, seed=1000 + F * 7 + E)
+    g = torch.Generator().manual_seed(F * 131 + E)
+    B = 71                                               # odd: the last wave-group is short
+    ids = torch.randint(0, nfeat, (B, F), generator=g)
+    vals = torch.rand(B, F, generator=g) * 1.2 - 0.1
+    v = vals.numpy().copy()
+    want = orc.arm_block(variant, ids.numpy(), v, sd, float(alpha))
+    with torch.no_grad():
+        got = m.arm_block(ids.to(DEV), vals.clone().to(DEV))
+        got32 = m.arm_block(ids.to(DEV).to(torch.int32), vals.clone().to(DEV))
+        m.kernel_flags = native.F_FORCE_GENERIC
+        gen = m.arm_block(ids.to(DEV), vals.clone().to(DEV))
+    assert _rel_err(got.cpu().numpy(), want) <= TOL
+    assert _rel_err(gen.cpu().numpy(), want) <= TOL
+    assert torch.equal(got, got32)
+
+
+def test_nonfinite_embedding_row_poisons_only_the_samples_that_use_it():
+    """a NaN / inf embedding row makes the reference's output non-finite for exactly the samples whose ids hit
+    it; nfield = 39 has a pad row per sample in the kernel's tile, which must not carry it to the group neighbour"""
+    meta, m, sd = _random_model("1h", 39, 97, 16, 2.0, 32, 1, seed=5)
+    g = torch.Generator().manual_seed(6)
+    B = 64
+    ids = torch.randint(2, 97, (B, 39), generator=g)
+    vals = torch.rand(B, 39, generator=g)
+    ids[0, 0] = 0                # first element of a wave-group: what a pad lane re-reads
+    ids[9, 38] = 1
+    with torch.no_grad():
+        m.embedding.embedding.weight[0, 3] = float("nan")
+        m.embedding.embedding.weight[1, :] = float("inf")
+        got = m.arm_block(ids.to(DEV), vals.clone().to(DEV)).cpu().numpy()
+    sd["embedding.embedding.weight"] = m.embedding.embedding.weight.detach().cpu().numpy()
+    want = orc.arm_block("1h", ids.numpy(), vals.numpy().copy(), sd, 2.0)
+    bad = np.zeros(B, bool); bad[[0, 9]] = True
+    assert (~np.isfinite(want[bad])).any(axis=(1, 2)).all() and np.isfinite(want[~bad]).all()
+    assert np.isfinite(got[~bad]).all()
+    assert (np.isfinite(got) == np.isfinite(want)).all()
+    assert _rel_err(got[~bad], want[~bad]) <= TOL
+
+
 def test_nan_value_poisons_only_its_own_sample():
     """clamp_(NaN) stays NaN in the reference (armnet_1h.py:81) and makes that sample's neurons NaN;
     the other samples of the same wave-group are untouched (compared with the oracle)."""

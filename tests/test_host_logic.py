@@ -41,6 +41,26 @@ def test_abi_argument_validation_without_device():
         native.check(native.ERR_UNSUPPORTED)
 
 
+def test_kernel_selection_covers_the_reference_run_sh_shapes():
+    """host-only query: the matrix-core kernel serves every block shape of the reference's run.sh (nemb = 10,
+    train.py's default) and BASELINE.json's configs; the documented exceptions go to the generic kernel"""
+    from armnet_hip import native
+    k = native.fused_kernel_kind
+    run_sh = [(10, 256), (10, 16), (3, 16), (3, 8), (22, 32), (22, 64), (39, 256), (39, 128), (43, 32), (43, 512),
+              (10, 128), (3, 128), (22, 128), (43, 128)]          # (nfield, nhead * nhid)
+    for F, O in run_sh:
+        assert k(F, 10, O, 2.0) == 1 and k(F, 10, O, 1.5) == 1 and k(F, 10, O, 1.7) == 1 and k(F, 10, O, 1.0) == 1
+    for F, E, O in [(10, 10, 10), (39, 16, 32), (39, 16, 128), (39, 64, 32), (22, 32, 128)]:   # BASELINE.json configs
+        assert k(F, E, O, 2.0) == 1
+    assert k(39, 10, 128, 2.5) == 0                               # alpha > 2: the faithful bisection
+    assert k(39, 10, 128, 2.0, n_iter=10) == 0                    # too few iterations to have converged
+    assert k(39, 10, 128, 2.0, flags=native.F_FAITHFUL_BISECT) == 0
+    assert k(39, 10, 128, 2.0, flags=native.F_FORCE_GENERIC) == 0
+    assert k(39, 11, 128, 2.0) == 0 and k(39, 128, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
+    with pytest.raises(native.ArmnetNativeError):
+        k(0, 16, 32, 2.0)
+
+
 @pytest.mark.parametrize("name", [n for n in model_cases() if n.endswith("fresh")])
 def test_same_seed_gives_reference_initial_weights(name):
     """Constructor order and initialisers match the reference (armnet_1h.py:59-74, armnet.py:63-75)."""
