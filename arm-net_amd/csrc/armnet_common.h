@@ -236,10 +236,35 @@ struct FusedArgs {
     SparseMapCfg cfg;
 };
 
+struct BwdArgs {
+    int64_t B;
+    int F, E, O;
+    const void* ids;
+    int id_type;
+    const float* vals;      // already clamped by the forward
+    const float* table;
+    int64_t nfeat;
+    const float* q_fold;    // [O,E]
+    const float* values;    // [O,F]
+    int O_all;              // neurons per sample in z / dz (0 = O): the MFMA kernel works on slices
+    const float* z;         // [B,O_all,E] forward output (pre-BN neurons)
+    const float* dz;        // [B,O_all,E]
+    float* d_table;         // [nfeat,E]  += (caller zero-initialises)
+    float* d_values;        // [O,F]      +=
+    float* d_qfold;         // [O,E]      +=
+    SparseMapCfg cfg;
+    float alpha;
+    uint32_t flags;
+};
+
 int launch_fused_generic(const FusedArgs& a, hipStream_t s);
 // returns ARMNET_ERR_UNSUPPORTED when the shape has no MFMA specialisation
 int launch_fused_mfma(const FusedArgs& a, hipStream_t s);
 bool fused_mfma_supports(int F, int E, int O);
+int launch_fused_bwd(const BwdArgs& a, hipStream_t s);
+// matrix-core backward; ARMNET_ERR_UNSUPPORTED when the shape has no instantiation
+int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t s);
+bool fused_bwd_mfma_supports(int F, int E, int O);
 
 int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
                         const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s);

@@ -18,24 +18,6 @@
 
 namespace armnet {
 
-struct BwdArgs {
-    int64_t B;
-    int F, E, O;
-    const void* ids;
-    int id_type;
-    const float* vals;      // already clamped by the forward
-    const float* table;
-    int64_t nfeat;
-    const float* q_fold;    // [O,E]
-    const float* values;    // [O,F]
-    const float* z;         // [B,O,E] forward output (pre-BN neurons)
-    const float* dz;        // [B,O,E]
-    float* d_table;         // [nfeat,E]  += (caller zero-initialises)
-    float* d_values;        // [O,F]      +=
-    float* d_qfold;         // [O,E]      +=
-    SparseMapCfg cfg;
-    float alpha;
-};
 
 template <typename IdT, int TPB>
 __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
@@ -171,6 +153,10 @@ static int launch_bwd_t(const BwdArgs& a, hipStream_t st) {
 
 int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
+    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && a.cfg.mode != SOLVE_BISECT && fused_bwd_mfma_supports(a.F, a.E, a.O)) {
+        const int rc = launch_fused_bwd_mfma(a, st);
+        if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
+    }
     if (a.O <= 128)
         return a.id_type == ARMNET_ID_I64 ? launch_bwd_t<int64_t, 128>(a, st) : launch_bwd_t<int32_t, 128>(a, st);
     if (a.O <= 256)
@@ -200,5 +186,6 @@ extern "C" int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha,
     a.d_table = d_table; a.d_values = d_values; a.d_qfold = d_qfold;
     a.cfg = make_sparse_cfg(alpha, n_iter, F, 1, flags);
     a.alpha = alpha;
+    a.flags = flags;
     return launch_fused_bwd(a, (hipStream_t)stream);
 }

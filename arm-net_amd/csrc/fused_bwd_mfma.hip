@@ -1,0 +1,41 @@
+// fused_bwd_mfma.hip — shape dispatch of the matrix-core backward kernel (fused_bwd_mfma_kernel.h).
+#include "fused_bwd_mfma_kernel.h"
+
+namespace armnet {
+
+// nemb even and <= 64 (8-byte staging chunks only up to 16), nfield <= 48; any neuron count (slices)
+bool fused_bwd_mfma_supports(int F, int E, int O) {
+    if (E < 2 || E > 64 || (E & 1) || O < 1 || F < 1 || F > 48) return false;
+    if (E > 16 && E % 4 != 0) return false;
+    return true;
+}
+
+int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
+    if (a.B == 0) return ARMNET_OK;
+    if (!fused_bwd_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
+    if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    const int nq = (((a.F + 3) / 4) + 1) & ~1;
+    const bool c16 = (a.E % 4 == 0);
+    if (((uintptr_t)a.table % (c16 ? 16 : 8))) return ARMNET_ERR_UNSUPPORTED;
+    if (a.E % 16 == 0 && (((uintptr_t)a.z % 16) || ((uintptr_t)a.dz % 16))) return ARMNET_ERR_UNSUPPORTED;
+    // slices of kBwdSlice neurons: each re-stages the rows and adds its part of dx to the table gradient
+    for (int o0 = 0; o0 < a.O; o0 += kBwdSlice) {
+        BwdArgs s = a;
+        s.O = a.O - o0 < kBwdSlice ? a.O - o0 : kBwdSlice;
+        s.O_all = a.O_all ? a.O_all : a.O;
+        s.q_fold = a.q_fold + (size_t)o0 * a.E;
+        s.values = a.values + (size_t)o0 * a.F;
+        s.z = a.z + (size_t)o0 * a.E;
+        s.dz = a.dz + (size_t)o0 * a.E;
+        s.d_values = a.d_values + (size_t)o0 * a.F;
+        s.d_qfold = a.d_qfold + (size_t)o0 * a.E;
+        int rc;
+        if (a.E <= 16) rc = c16 ? launch_bwd_mfma_e16_c16(s, nq, st) : launch_bwd_mfma_e16_c8(s, nq, st);
+        else if (a.E <= 32) rc = launch_bwd_mfma_e32_c16(s, nq, st);
+        else rc = launch_bwd_mfma_e64_c16(s, nq, st);
+        if (rc != ARMNET_OK) return rc;
+    }
+    return ARMNET_OK;
+}
+
+}  // namespace armnet

@@ -1,0 +1,18 @@
+// fused_bwd_mfma_e64c16.hip — instantiations of the matrix-core backward kernel for nemb padded to 64, 16-byte staging chunks.
+#include "fused_bwd_mfma_kernel.h"
+
+namespace armnet {
+
+int launch_bwd_mfma_e64_c16(const BwdArgs& a, int nq, hipStream_t st) {
+    switch (nq) {
+        case 2: return launch_bwd_src<64, 2, 16>(a, st);
+        case 4: return launch_bwd_src<64, 4, 16>(a, st);
+        case 6: return launch_bwd_src<64, 6, 16>(a, st);
+        case 8: return launch_bwd_src<64, 8, 16>(a, st);
+        case 10: return launch_bwd_src<64, 10, 16>(a, st);
+        case 12: return launch_bwd_src<64, 12, 16>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace armnet

@@ -1,0 +1,562 @@
+// fused_bwd_mfma_kernel.h — backward of the fused ARM block on the CDNA4 matrix cores (gfx950), fp32.
+// Template + launcher; instantiated per family in fused_bwd_mfma_*.hip.  Math as in fused_bwd.hip (the
+// shape-agnostic kernel this one replaces where it applies); layouts as in fused_mfma_kernel.h.
+//
+// One WAVE owns one sample at a time (wave-private LDS, no block barrier between prologue and flush).
+// Per sample the scaled rows X[f, :] are staged once; then per pass of 16 neurons:
+//
+//   MFMA #1   gates  G[f, o] = X[f, :] . q_fold[o, :]              (as the forward)
+//   solve     p[o, :] = entmax / softmax of the row, normalised      (as the forward, one sample per wave)
+//   MFMA #3   dW[f, o] = X[f, :] . ds[o, :],  ds = dz * z            same shape as #1, B operand from HBM:
+//             a lane's 16-byte dz / z loads are exactly its B-operand k-steps
+//   VALU      d_values += p * dW (per-wave register accumulators over all its samples);  dp = values * dW;
+//             dg = J_entmax(p)^T dp (entmax.py:70-80: one 4-lane-group reduction);  w = p * values
+//   MFMA #4   dq_fold^T[e, o] += sum_f X[f, e] dg[o, f]              same shape as the forward's #2 (dg in the
+//             C layout IS its B operand); the accumulator tile lives over all samples of the wave
+//   MFMA #5   dx[f, e] += sum_o w[o, f] ds[o, e] + dg[o, f] q_fold[o, e]     contraction over the NEURONS, which
+//             the C layouts keep in the low lane bits: w and dg go through a transposing LDS buffer
+//             ([o][tile row], 16-byte writes, 4-byte operand reads); ds is read back from LDS in k = o form.
+//             The dx tiles stay in accumulators over all passes.
+//   scatter   d_table[id[f], :] += dx[f, :] * val[f]                global float atomics (64-byte runs)
+//
+// MFMAs per sample and pass (nemb = 16, nfield = 39): 12 + 12 + 10 + 24 = 58 (forward: 20).
+#pragma once
+#include "fused_mfma_kernel.h"
+
+namespace armnet {
+
+constexpr int kBwdSlice = 32;     // neurons per launch = 2 passes: the d_values / d_qfold accumulators of a slice
+                                  // stay in registers over all samples of a wave (LDS float atomics from 4 waves on
+                                  // the same addresses cost more than the rest of the kernel: measured 888 -> 368 us)
+constexpr int kBwdNT = kBwdSlice / 16;
+
+template <int E, int NQ, int MODE, int SRC, int CB>
+__global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
+    constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
+    constexpr int ROWS = NTILE * 16;
+    constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
+    constexpr int CF = CB / 4, CH = E / CF, RPI = 64 / CH, NI = ROWS / RPI;
+    constexpr int EB = E / 16, NP = NQ / 2;
+    constexpr int RS = ROWS + 4;              // row stride of the transposing buffers
+    constexpr int FP = 4 * NQ;                // nfield padded
+    constexpr int XT = ROWS * ES, RED = 128, TW = 16 * RS, DSL = 16 * ES, IDV = 2 * ROWS;
+    constexpr int WAVE_FLOATS = XT + RED + 2 * TW + DSL + IDV;
+    static_assert(E % 16 == 0 && ROWS % RPI == 0 && NQ % 2 == 0 && (CB == 16 || CB == 8), "shape");
+    using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
+
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int F = a.F, O = a.O, Er = a.E;
+    const int O_all = a.O_all ? a.O_all : O;
+    const int NT = (O + 15) / 16, OP = NT * 16;
+    float* xt = lds_all + wave * WAVE_FLOATS;
+    float* red = xt + XT;
+    float* tw = red + RED;                    // [16 o][RS]  w = p * values, transposed
+    float* tg = tw + TW;                      // [16 o][RS]  dg, transposed
+    float* dsl = tg + TW;                     // [16 o][ES]  ds = dz * z of this pass
+    uint32_t* idl = reinterpret_cast<uint32_t*>(dsl + DSL);   // [ROWS] table row of each tile row (~0u: pad row)
+    float* vll = dsl + DSL + ROWS;            // [ROWS] value of each tile row
+    // block-shared
+    float* p_bq = lds_all + 4 * WAVE_FLOATS;  // [NT][EB][64] f32x4   q_fold as the B operand of MFMA #1
+    float* p_vv = p_bq + NT * EB * 64 * 4;    // [NT][NP][64] f32x2   values in the C layout
+    float* qfl = p_vv + NT * NP * 64 * 2;     // [OP][ES]            q_fold, plain (B operand of MFMA #5)
+    float* acc_dv = qfl + OP * ES;            // [OP][FP]
+    float* acc_dq = acc_dv + OP * FP;         // [OP][E]
+
+    const int Bi = (int)a.B;
+    const int nwaves = (int)gridDim.x * 4;
+
+    // ---- staging geometry (one sample per wave): fused_mfma_kernel.h with SPW = 1 -------------------
+    const int chunk = lane % CH;
+    const bool chunk_ok = (chunk + 1) * CF <= Er;
+    int fld[NI];         // field of the row this lane stages in instruction n (0 for a pad row)
+    bool pad[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int row = n * RPI + lane / CH;
+        const int q = 4 * (row >> 4) + (row & 3);
+        const int f = 4 * q + ((row & 15) >> 2);
+        pad[n] = !(q < NQ && f < F);
+        fld[n] = pad[n] ? 0 : f;
+    }
+    const float padneg_a = ((4 * (NQ - 1) + g) >= F) ? -INFINITY : 0.f;
+    const float padneg_b = (NQ >= 2 && (4 * (NQ - 2) + g) >= F) ? -INFINITY : 0.f;
+    const bool two_pad = F <= 4 * (NQ - 1);
+    const uint32_t id_max = (uint32_t)a.nfeat - 1u;
+    const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
+    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(a.table) + chunk * CB
+                                    : reinterpret_cast<const char*>(kZeroRow);
+    constexpr int XQ = 4 * NTILE - NQ;
+    constexpr int NZ = ((7 + 4 * XQ) * (E / 4) + 63) / 64;
+    const int npf = 4 * NQ - F;
+    int zoff[NZ];
+#pragma unroll
+    for (int m = 0; m < NZ; ++m) {
+        const int idx = lane + 64 * m;
+        const int cc = idx % (E / 4), kk = idx / (E / 4);
+        int q, gg;
+        if (kk < npf) {
+            const int f = F + kk;
+            q = f >> 2;
+            gg = f & 3;
+        } else {
+            const int x = kk - npf;
+            q = NQ + (x >> 2);
+            gg = x & 3;
+        }
+        zoff[m] = (q < 4 * NTILE) ? ((q >> 2) * 16 + 4 * gg + (q & 3)) * ES + 4 * cc : -1;
+    }
+    const bool full_rows = (Er == E);
+    // ablation switches for profiling (tools/bwd_bench.py --flags); never set by the product path
+    const bool dbg_no_scatter = (a.flags & 0x400u) != 0;   // skip the d_table atomics
+    const bool dbg_one_pass = (a.flags & 0x2000u) != 0;    // only the first 16-neuron pass
+    const bool dbg_hot_rows = (a.flags & 0x200u) != 0;     // fold ids into 1024 rows
+
+    // ---- block prologue: parameters of this neuron slice, zeroed accumulators -------------------------
+    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+        const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
+        const int o = 16 * nt + (l & 15);
+        const int e0 = 16 * kb + 4 * (l >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (o < O)
+            for (int r = 0; r < 4; ++r)
+                if (e0 + r < Er) v[r] = a.q_fold[(size_t)o * Er + e0 + r];
+        *reinterpret_cast<f32x4*>(p_bq + i * 4) = v;
+    }
+    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
+        const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
+        const int o = 16 * nt + (l & 15);
+        const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
+        f32x2 v;
+        v[0] = (o < O && f0 < F) ? a.values[(size_t)o * F + f0] : 0.f;
+        v[1] = (o < O && f1 < F) ? a.values[(size_t)o * F + f1] : 0.f;
+        *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
+    }
+    for (int i = threadIdx.x; i < OP * ES; i += 256) {
+        const int o = i / ES, e = i - o * ES;
+        qfl[i] = (o < O && e < Er) ? a.q_fold[(size_t)o * Er + e] : 0.f;
+    }
+    for (int i = threadIdx.x; i < OP * (FP + E); i += 256) acc_dv[i] = 0.f;     // acc_dv and acc_dq are contiguous
+    __syncthreads();
+
+    const float am1 = a.cfg.am1;
+    const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
+    const float invF = 1.0f / (float)F;
+    const float tau_off = a.cfg.tau_hi_off;
+    const float L2E = 1.44269502162933349609375f;
+    const float two_m_alpha = 2.0f - a.alpha;
+
+    // per-wave accumulators over all its samples: d_values in the C layout, d_qfold^T as MFMA #4's accumulator
+    float dvacc[kBwdNT][NQ];
+    f32x4 dqacc[kBwdNT][EB];
+#pragma unroll
+    for (int n = 0; n < kBwdNT; ++n) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dvacc[n][j] = 0.f;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) dqacc[n][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int b = (int)blockIdx.x * 4 + wave; b < Bi; b += nwaves) {
+        // ---- stage the sample's rows (scaled) into the wave's tile; remember id / value per tile row ----
+        wave_lds_fence();
+        {
+            uint32_t idr[NI];
+            float vr[NI];
+            RowT rw[NI];
+            const size_t e0 = (size_t)b * F;
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                uint32_t lo, hi = 0u;
+                if constexpr (SRC == 0) {
+                    const uint2 w = reinterpret_cast<const uint2*>(a.ids)[e0 + fld[n]];
+                    lo = w.x;
+                    hi = w.y;
+                } else {
+                    lo = reinterpret_cast<const uint32_t*>(a.ids)[e0 + fld[n]];
+                }
+                idr[n] = (hi != 0u || lo > id_max) ? 0u : lo;      // the forward already raised on bad ids
+                if (dbg_hot_rows) idr[n] &= 1023u;
+                vr[n] = a.vals[e0 + fld[n]];
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) rw[n] = *reinterpret_cast<const RowT*>(row_base + (size_t)idr[n] * row_bytes);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const int row = n * RPI + lane / CH;
+                *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = rw[n] * vr[n];
+                if (chunk == 0) {
+                    idl[row] = pad[n] ? 0xffffffffu : idr[n];
+                    vll[row] = vr[n];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NZ; ++m)
+                if (zoff[m] >= 0) *reinterpret_cast<f32x4*>(xt + zoff[m]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wave_lds_fence();
+
+        f32x4 cdx[NTILE][EB];
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb) cdx[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int nt = 0; nt < kBwdNT; ++nt) {
+            if (nt >= (dbg_one_pass ? 1 : NT)) break;                   // wave-uniform
+            // ---- ds = dz * z of this lane's neuron: the B operand of MFMA #3 (issue the loads first) --------
+            const int o = 16 * nt + c;
+            f32x4 ds4[EB];
+            {
+                const size_t zo = ((size_t)b * O_all + o) * (size_t)Er + 4 * g;
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+                    if (o < O) {
+                        if (full_rows) {
+                            z4 = *reinterpret_cast<const f32x4*>(a.z + zo + 16 * eb);
+                            d4 = *reinterpret_cast<const f32x4*>(a.dz + zo + 16 * eb);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * eb + 4 * g + r < Er) {
+                                    z4[r] = a.z[zo + 16 * eb + r];
+                                    d4[r] = a.dz[zo + 16 * eb + r];
+                                }
+                        }
+                    }
+                    ds4[eb] = z4 * d4;
+                }
+            }
+            // ---- MFMA #1: gates -------------------------------------------------------------------------
+            f32x4 c1[NTILE];
+#pragma unroll
+            for (int kb = 0; kb < EB; ++kb) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
+                f32x4 av[NTILE];
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t)
+                    av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) {
+                        if (kb == 0 && kk == 0)
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
+                    }
+            }
+#define XG(j) c1[(j) >> 2][(j) & 3]
+#define XP_GET(jp) (f32x2{XG(2 * (jp)), XG(2 * (jp) + 1)})
+#define XP_SET(jp, v)            \
+    do {                         \
+        const f32x2 _v = (v);    \
+        XG(2 * (jp)) = _v[0];    \
+        XG(2 * (jp) + 1) = _v[1]; \
+    } while (0)
+            const float* vv_base = p_vv + (nt * NP * 64 + lane) * 2;
+#define VV(jp) (*reinterpret_cast<const f32x2*>(vv_base + (jp) * 128))
+
+            // ---- sparse map: p (normalised) left in the gate registers -------------------------------------
+            wave_lds_fence();
+            float tau, Ssum = 1.0f;
+            {
+                f32x2 sm2;
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) {
+                    f32x2 x = XP_GET(jp);
+                    if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
+                        x *= f32x2{am1, am1};
+                        XP_SET(jp, x);
+                    }
+                    sm2 = jp == 0 ? x : sm2 + x;
+                }
+                XG(NQ - 1) += padneg_a;
+                if (two_pad) XG(NQ - 2) += padneg_b;
+                float mx = XG(0);
+#pragma unroll
+                for (int j = 1; j < NQ; ++j) mx = vmax2(mx, XG(j));
+                red_write(red, 0, lane, mx, sm2[0] + sm2[1]);
+                wave_lds_fence();
+                const Red2 r = red_read(red, 0, c);
+                mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
+                const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                if constexpr (MODE == SOLVE_SOFTMAX) tau = mx + (sm - sm);
+                else tau = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
+            }
+            if constexpr (MODE == SOLVE_SOFTMAX) {
+                wave_lds_fence();
+                float S = 0.f;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const float p = __builtin_amdgcn_exp2f((XG(j) - tau) * L2E);
+                    S += p;
+                    XG(j) = p;
+                }
+                red_write(red, 0, lane, S, 0.f);
+                wave_lds_fence();
+                const Red2 q = red_read(red, 0, c);
+                Ssum = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
+            } else {
+                f32x2 pkeep[MODE == SOLVE_NEWTON ? NP : 1];
+                for (int it = 0; it < kNewtonMaxIter; ++it) {
+                    wave_lds_fence();
+                    const f32x2 tk = {tau, tau};
+                    f32x2 S2, D2;
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const f32x2 t = pk_sub_clamp01(XP_GET(jp), tk);
+                        f32x2 sv, dv;
+                        if constexpr (MODE == SOLVE_MICHELOT) {
+                            sv = t;
+                            dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
+                        } else if constexpr (MODE == SOLVE_NEWTON15) {
+                            sv = t * t;
+                            dv = t;
+                        } else {
+                            f32x2 u;
+                            u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
+                            u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
+                            sv = u * t;
+                            dv = u;
+                            pkeep[jp] = sv;
+                        }
+                        S2 = jp == 0 ? sv : S2 + sv;
+                        D2 = jp == 0 ? dv : D2 + dv;
+                    }
+                    red_write(red, 0, lane, S2[0] + S2[1], D2[0] + D2[1]);
+                    wave_lds_fence();
+                    const Red2 r = red_read(red, 0, c);
+                    const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);
+                    float Dv = sd[1];
+                    if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
+                    if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
+                    Ssum = sd[0];
+                    const float f = sd[0] - 1.0f;
+                    const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau);
+                    const bool act = (f > kNewtonTol) && (tn > tau);
+                    tau = act ? tn : tau;
+                    if (!__builtin_amdgcn_ballot_w64(act)) break;
+                }
+                const f32x2 tk = {tau, tau};
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) {
+                    f32x2 p;
+                    if constexpr (MODE == SOLVE_NEWTON) {
+                        p = pkeep[jp];
+                    } else {
+                        const f32x2 t = pk_sub_clamp01(XP_GET(jp), tk);
+                        if constexpr (MODE == SOLVE_MICHELOT) p = t;
+                        else p = t * t;
+                    }
+                    XP_SET(jp, p);
+                }
+            }
+            {
+                const float S = Ssum + (tau - tau);
+                float r = __builtin_amdgcn_rcpf(S);
+                r = fmaf(fmaf(-S, r, 1.0f), r, r);
+                const f32x2 r2 = {r, r};
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) XP_SET(jp, XP_GET(jp) * r2);
+            }
+
+            // ---- MFMA #3: dW[f, o] = X[f, :] . ds[o, :] (layout of the gates) -------------------------------
+            f32x4 c3[NTILE];
+#pragma unroll
+            for (int kb = 0; kb < EB; ++kb) {
+                f32x4 av[NTILE];
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t)
+                    av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) {
+                        if (kb == 0 && kk == 0)
+                            c3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], ds4[kb][kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            c3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], ds4[kb][kk], c3[t], 0, 0, 0);
+                    }
+            }
+#define DG(j) c3[(j) >> 2][(j) & 3]
+            // ds in LDS for the k = neuron contraction of MFMA #5 (rows of padding neurons are zero)
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb) *reinterpret_cast<f32x4*>(dsl + c * ES + 16 * eb + 4 * g) = ds4[eb];
+
+            // ---- d_values, dp, entmax / softmax Jacobian-vector product -------------------------------------
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float p = XG(j), dW = DG(j);
+                const float v = VV(j >> 1)[j & 1];
+                dvacc[nt][j] = fmaf(p, dW, dvacc[nt][j]);
+                const float dp = v * dW;
+                if constexpr (MODE == SOLVE_SOFTMAX) {
+                    DG(j) = dp;
+                    s1 = fmaf(p, dp, s1);
+                } else {
+                    float gp;
+                    if constexpr (MODE == SOLVE_MICHELOT) gp = p > 0.f ? 1.0f : 0.f;
+                    else if constexpr (MODE == SOLVE_NEWTON15) gp = __builtin_sqrtf(p);
+                    else gp = p > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p)) : 0.f;
+                    const float dxp = dp * gp;
+                    DG(j) = dxp;
+                    s1 += dxp;
+                    s2 += gp;
+                }
+            }
+            wave_lds_fence();
+            red_write(red, 0, lane, s1, s2);
+            wave_lds_fence();
+            float qv;
+            {
+                const Red2 r = red_read(red, 0, c);
+                const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);
+                qv = (MODE == SOLVE_SOFTMAX) ? sd[0] : sd[0] / sd[1];
+            }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float p = XG(j);
+                if constexpr (MODE == SOLVE_SOFTMAX) {
+                    DG(j) = p * (DG(j) - qv);
+                } else {
+                    float gp;
+                    if constexpr (MODE == SOLVE_MICHELOT) gp = p > 0.f ? 1.0f : 0.f;
+                    else if constexpr (MODE == SOLVE_NEWTON15) gp = __builtin_sqrtf(p);
+                    else gp = p > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p)) : 0.f;
+                    DG(j) = fmaf(-qv, gp, DG(j));
+                }
+                XG(j) = p * VV(j >> 1)[j & 1];                           // w = p * values
+            }
+            // ---- w and dg transposed ([o][tile row]) for the contraction over neurons ------------------------
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c1[t];
+                *reinterpret_cast<f32x4*>(tg + c * RS + 16 * t + 4 * g) = c3[t];
+            }
+            // ---- MFMA #4: dq_fold^T[e, o] += sum_f X[f, e] dg[o, f], accumulated over the wave's samples ------
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    const int row = 16 * (j >> 2) + 4 * g + (j & 3);
+                    const float a2 = xt[row * ES + 16 * eb + c];
+                    dqacc[nt][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, DG(j), dqacc[nt][eb], 0, 0, 0);
+                }
+            // ---- MFMA #5: dx[f, e] += sum_o w[o, f] ds[o, e] + dg[o, f] q_fold[o, e] ------------------------------
+            wave_lds_fence();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ol = 4 * kk + g;                               // k index of this lane: neuron within the pass
+                float b1[EB], b2[EB];
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    b1[eb] = dsl[ol * ES + 16 * eb + c];
+                    b2[eb] = qfl[(16 * nt + ol) * ES + 16 * eb + c];
+                }
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t) {
+                    const float a1 = tw[ol * RS + 16 * t + c];
+                    const float a2 = tg[ol * RS + 16 * t + c];
+#pragma unroll
+                    for (int eb = 0; eb < EB; ++eb) {
+                        cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdx[t][eb], 0, 0, 0);
+                        cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2[eb], cdx[t][eb], 0, 0, 0);
+                    }
+                }
+            }
+            wave_lds_fence();
+#undef XG
+#undef XP_GET
+#undef XP_SET
+#undef VV
+#undef DG
+        }
+        // ---- scatter: d_table[id[f], e] += dx[f, e] * val[f]   (x = table[id] * val, layers.py:20-21) ----------
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * g + r;
+                const uint32_t id = idl[row];
+                const float v = vll[row];
+                if (id != 0xffffffffu && !dbg_no_scatter) {
+                    float* dst = a.d_table + (size_t)id * Er + c;
+#pragma unroll
+                    for (int eb = 0; eb < EB; ++eb)
+                        if (16 * eb + c < Er) unsafeAtomicAdd(dst + 16 * eb, cdx[t][eb][r] * v);
+                }
+            }
+    }
+    // ---- wave accumulators -> block accumulators (LDS atomics, once per wave) -> global ------------------------
+#pragma unroll
+    for (int nt = 0; nt < kBwdNT; ++nt) {
+        if (nt >= NT) break;
+        float* dv_row = acc_dv + (16 * nt + c) * FP + g;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) atomicAdd(dv_row + 4 * j, dvacc[nt][j]);        // pad slots receive zeros
+        float* dq_row = acc_dq + (16 * nt + c) * E + 4 * g;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(dq_row + 16 * eb + r, dqacc[nt][eb][r]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < O * F; i += 256) {
+        const int o = i / F, f = i - o * F;
+        unsafeAtomicAdd(a.d_values + i, acc_dv[o * FP + f]);
+    }
+    for (int i = threadIdx.x; i < O * Er; i += 256) {
+        const int o = i / Er, e = i - o * Er;
+        unsafeAtomicAdd(a.d_qfold + i, acc_dq[o * E + e]);
+    }
+}
+
+template <int E, int NQ, int MODE, int SRC, int CB>
+static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
+    constexpr int NTILE = (NQ + 3) / 4, ROWS = NTILE * 16;
+    constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 2 * 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
+    const int NT = (a.O + 15) / 16, OP = NT * 16;
+    const size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
+                        (size_t)OP * (E + 4) + (size_t)OP * (4 * NQ) + (size_t)OP * E) * sizeof(float);
+    if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    int per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > 2) per_cu = 2;
+    const int64_t blocks = (a.B + 3) / 4;
+    const int64_t resident = 256 * (int64_t)per_cu;
+    const int64_t want = blocks < resident ? blocks : resident;
+    auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC, CB>;
+    if (lds > 64 * 1024)
+        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<(int)want, 256, lds, st>>>(a);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+template <int E, int NQ, int CB>
+static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
+#define ARMNET_BWD_MODE(SRC)                                                                         \
+    switch (a.cfg.mode) {                                                                            \
+        case SOLVE_SOFTMAX: return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, SRC, CB>(a, st);             \
+        case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC, CB>(a, st);           \
+        case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC, CB>(a, st);           \
+        case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC, CB>(a, st);               \
+        default: return ARMNET_ERR_UNSUPPORTED;                                                      \
+    }
+    if (a.id_type == ARMNET_ID_I64) { ARMNET_BWD_MODE(0) }
+    ARMNET_BWD_MODE(1)
+#undef ARMNET_BWD_MODE
+}
+
+int launch_bwd_mfma_e16_c16(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e16_c8(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e32_c16(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e64_c16(const BwdArgs& a, int nq, hipStream_t st);
+
+}  // namespace armnet

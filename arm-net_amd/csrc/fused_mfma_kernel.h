@@ -40,7 +40,7 @@
 namespace armnet {
 
 // 16 zero bytes in device memory: what a staging lane reads when its chunk is padding
-__device__ float kZeroRow[4] = {0.f, 0.f, 0.f, 0.f};   // not const: keeps the select with the table pointer in the global address space
+static __device__ float kZeroRow[4] = {0.f, 0.f, 0.f, 0.f};   // not const: keeps the select with the table pointer in the global address space
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -73,3 +73,42 @@ def test_a_few_adam_steps_reduce_the_loss():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+# (nfield, nemb, neurons, alpha): every staging family and solver mode of the matrix-core backward, neuron counts that
+# need padding and more than one 64-neuron slice
+BWD_SWEEP = [(1, 2, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5), (9, 14, 33, 1.0), (13, 8, 16, 2.0),
+             (17, 18, 5, 2.0), (22, 32, 32, 2.0), (22, 10, 64, 1.5), (25, 28, 70, 1.5), (31, 32, 64, 1.0),
+             (39, 16, 32, 2.0), (39, 16, 32, 1.5), (39, 16, 32, 1.7), (39, 16, 32, 1.0), (39, 10, 128, 2.0),
+             (43, 10, 96, 1.7), (47, 8, 19, 2.0), (48, 64, 24, 2.0), (39, 64, 32, 1.5), (30, 40, 20, 1.7), (6, 60, 7, 1.0)]
+
+
+@pytest.mark.parametrize("F,E,O,alpha", BWD_SWEEP)
+def test_mfma_backward_agrees_with_the_generic_backward(F, E, O, alpha):
+    """armnet_fused_bwd_f32: the matrix-core kernel against the shape-agnostic kernel (which the reference's
+    gradients above pin) on the same random inputs, through the C ABI; also int32 ids"""
+    from armnet_hip import native
+    g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
+    B, nfeat = 37, 53
+    table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
+    qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+    values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+    one, zero = torch.ones(O, device=DEV), torch.zeros(O, device=DEV)
+    z = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, one, zero, z)
+    dz = torch.randn(B, O, E, generator=g).to(DEV)
+
+    def run(flags, idt):
+        dt, dv, dq = torch.zeros_like(table), torch.zeros_like(values), torch.zeros_like(qf)
+        native.fused_bwd(B, F, E, O, alpha, 50, flags, idt, vals, table, qf, values, z, dz, dt, dv, dq)
+        return dt, dv, dq
+
+    want = run(native.F_FORCE_GENERIC, ids)
+    got = run(0, ids)
+    got32 = run(0, ids.to(torch.int32))
+    for name, a, b, c in zip(("d_table", "d_values", "d_qfold"), got, want, got32):
+        scale = max(float(b.abs().max()), 1e-12)
+        assert float((a - b).abs().max()) / scale <= 2e-5, name
+        assert float((c - b).abs().max()) / scale <= 2e-5, name + " (int32 ids)"
