@@ -61,15 +61,104 @@ class _ArmBlockFn(torch.autograd.Function):
         d_qf = torch.zeros(O, E, device=dz.device, dtype=torch.float32)
         native.fused_bwd(B, F, E, O, alpha, n_iter, flags, ids.contiguous(), vals, table.detach(), qf,
                          values.detach().reshape(O, F).contiguous(), z, dz.contiguous(), d_table, d_values, d_qf)
-        scale = float(D) ** -0.5
-        if variant == native.ONE_HEAD:                      # q_fold = scale * query @ W,  W = bilinear_w [D,E]
-            d_q = scale * (d_qf @ bilinear_w.t())
-            d_w = scale * (query.t() @ d_qf)
-        else:                                               # q_fold[k,o,e] = scale * sum_y W[k,e,y] query[k,o,y]
-            g3 = d_qf.view(K, H, E)
-            d_q = scale * torch.einsum("koe,key->koy", g3, bilinear_w)
-            d_w = scale * torch.einsum("koe,koy->key", g3, query)
-        return d_table, d_w, d_q, d_values.view_as(values), None, None, None
+        return _arm_block_grads((variant, K, H, E, D), (bilinear_w, query, values), d_qf, d_table, d_values) + (None, None, None)
+
+
+def _arm_block_grads(ctx_cfg, tensors, d_qf, d_table, d_values):
+    """chain rule through the parameter fold (q_fold from bilinear_w and query)"""
+    variant, K, H, E, D = ctx_cfg
+    bilinear_w, query, values = tensors
+    scale = float(D) ** -0.5
+    if variant == native.ONE_HEAD:                      # q_fold = scale * query @ W,  W = bilinear_w [D,E]
+        d_q = scale * (d_qf @ bilinear_w.t())
+        d_w = scale * (query.t() @ d_qf)
+    else:                                               # q_fold[k,o,e] = scale * sum_y W[k,e,y] query[k,o,y]
+        g3 = d_qf.view(K, H, E)
+        d_q = scale * torch.einsum("koe,key->koy", g3, bilinear_w)
+        d_w = scale * torch.einsum("koe,koy->key", g3, query)
+    return d_table, d_w, d_q, d_values.view_as(values)
+
+
+class _ArmBlockBNFn(torch.autograd.Function):
+    """Training step of the block INCLUDING its training-mode BatchNorm1d (armnet_1h.py:85 / armnet.py:88-89):
+    forward = fused kernel (pre-BN neurons z) + batch statistics + normalise, all HIP; backward = the BatchNorm
+    reductions over (z, dy), then armnet_fused_bwd_bn_f32, which forms dz from dy inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, table, bilinear_w, query, values, bn_weight, bn_bias, ids, vals, cfg, bn_state):
+        variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
+        running_mean, running_var, momentum, eps = bn_state
+        dev = query.device
+        O = K * H
+        qf = torch.empty(O, E, device=dev, dtype=torch.float32)
+        one, zero = torch.ones(O, device=dev), torch.zeros(O, device=dev)
+        sc, sh = torch.empty(O, device=dev), torch.empty(O, device=dev)
+        native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
+                           one, zero, zero, one, 0.0, qf, sc, sh)
+        z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
+                              write_clamped_vals=True, check_ids=check_ids, flags=flags)
+        y, mean, rstd, _, _ = native.bn_forward_train(z, bn_weight.detach(), bn_bias.detach(), running_mean,
+                                                      running_var, momentum, eps, relu=False)
+        ctx.save_for_backward(table, bilinear_w, query, values, bn_weight, ids, vals, qf, z, mean, rstd)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        table, bilinear_w, query, values, bn_weight, ids, vals, qf, z, mean, rstd = ctx.saved_tensors
+        variant, K, H, E, D, alpha, n_iter, flags, _ = ctx.cfg
+        B, F = vals.shape
+        O = K * H
+        dy = dy.contiguous()
+        d_bnw, d_bnb, cA, cB, cC = native.bn_backward_coef(z, dy, bn_weight.detach(), mean, rstd)
+        d_table = torch.zeros_like(table)
+        d_values = torch.zeros(O, F, device=dy.device, dtype=torch.float32)
+        d_qf = torch.zeros(O, E, device=dy.device, dtype=torch.float32)
+        native.fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids.contiguous(), vals, table.detach(), qf,
+                            values.detach().reshape(O, F).contiguous(), z, dy, cA, cB, cC, d_table, d_values, d_qf)
+        d_table, d_w, d_q, d_v = _arm_block_grads((variant, K, H, E, D), (bilinear_w, query, values), d_qf, d_table,
+                                                  d_values)
+        return d_table, d_w, d_q, d_v, d_bnw, d_bnb, None, None, None, None
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """training-mode BatchNorm1d (+ optional fused ReLU) on [N,C] / [N,C,L] with the HIP passes of bn_kernels.hip"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        y, mean, rstd, scale, shift = native.bn_forward_train(x, weight.detach(), bias.detach(), running_mean,
+                                                              running_var, momentum, eps, relu)
+        ctx.save_for_backward(x, weight, mean, rstd, scale, shift)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd, scale, shift = ctx.saved_tensors
+        dy = dy.contiguous()
+        rs, rt = (scale, shift) if ctx.relu else (None, None)
+        d_w, d_b, cA, cB, cC = native.bn_backward_coef(x, dy, weight.detach(), mean, rstd, rs, rt)
+        dx = native.bn_backward_apply(x, dy, cA, cB, cC, rs, rt) if ctx.needs_input_grad[0] else None
+        return dx, d_w, d_b, None, None, None, None, None
+
+
+class HipBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters, buffers and state_dict keys) whose TRAINING forward/backward on the GPU
+    run as the HBM-bound HIP passes of bn_kernels.hip; eval mode and anything unusual (no affine, no running
+    stats, cumulative momentum, non-fp32, CPU) fall through to torch."""
+
+    def _hip_ok(self, x):
+        return (self.training and x.is_cuda and x.dtype == torch.float32 and self.affine and self.track_running_stats
+                and self.momentum is not None and x.dim() in (2, 3) and x.numel() // x.shape[1] > 1)
+
+    def forward(self, x, relu=False):
+        if not self._hip_ok(x):
+            y = super().forward(x)
+            return torch.relu(y) if relu else y
+        self.num_batches_tracked.add_(1)
+        return _BatchNormTrainFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                       float(self.momentum), float(self.eps), bool(relu))
 
 
 class HipEmbedding(nn.Module):
@@ -96,7 +185,7 @@ def build_mlp(ninput, nlayers, nhid, dropout, noutput=1):
     stack = []
     width = ninput
     for _ in range(nlayers):
-        stack += [nn.Linear(width, nhid), nn.BatchNorm1d(nhid), nn.ReLU(), nn.Dropout(p=dropout)]
+        stack += [nn.Linear(width, nhid), HipBatchNorm1d(nhid), nn.ReLU(), nn.Dropout(p=dropout)]
         width = nhid
     stack.append(nn.Linear(width, noutput))
     return nn.Sequential(*stack)
@@ -133,7 +222,7 @@ class ArmNetBase(nn.Module):
         self.nhead, self.nhid, self.alpha = nhead, nhid, float(alpha)
         self.embedding = HipEmbedding(nfeat, nemb)
         self.attn_layer = attn_layer()
-        self.arm_bn = nn.BatchNorm1d(nhead * nhid)
+        self.arm_bn = HipBatchNorm1d(nhead * nhid)
         self.mlp = _MLP(nhead * nhid * nemb, mlp_nlayer, mlp_nhid, dropout, noutput=noutput)
         if ensemble:
             self.deep_embedding = HipEmbedding(nfeat, nemb)
@@ -168,8 +257,15 @@ class ArmNetBase(nn.Module):
                 raise NotImplementedError("training with a row-sharded table is not supported")
             cfg = (self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), self.alpha, self.n_iter,
                    self.kernel_flags, self.check_ids)
+            bn = self.arm_bn
+            if (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                    and vals.shape[0] * self.nemb > 1):
+                bn.num_batches_tracked.add_(1)
+                return _ArmBlockBNFn.apply(self.embedding.embedding.weight, bw, at.query, at.values, bn.weight, bn.bias,
+                                           ids, vals, cfg, (bn.running_mean, bn.running_var, float(bn.momentum),
+                                                            float(bn.eps)))
             z = _ArmBlockFn.apply(self.embedding.embedding.weight, bw, at.query, at.values, ids, vals, cfg)
-            return self.arm_bn(z)
+            return bn(z)
         qf, sc, sh = self._folded.get(self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), bw, at.query,
                                       self.arm_bn)
         if getattr(self, "_shard", None) is not None:
@@ -259,7 +355,8 @@ class GraphedForward:
 class _MLP(nn.Module):
     """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*).
 
-    Training mode runs the nn.Sequential as is.  In eval mode on the GPU each (Linear, BatchNorm1d, ReLU,
+    Training mode on the GPU: hipBLASLt Linear, then BatchNorm1d + ReLU fused into the HIP passes of
+    bn_kernels.hip (HipBatchNorm1d).  In eval mode on the GPU each (Linear, BatchNorm1d, ReLU,
     Dropout) group collapses to ONE hipBLASLt GEMM with a bias+ReLU epilogue: the BN affine is folded into
     the Linear's weight and bias (W' = W * s, b' = b * s + t with s = gamma / sqrt(var + eps),
     t = beta - mean * s; refreshed when any source tensor's version counter moves)."""
@@ -281,7 +378,7 @@ class _MLP(nn.Module):
             with torch.no_grad():
                 while i < len(mods):
                     lin = mods[i]
-                    if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                    if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):   # HipBatchNorm1d is one
                         bn = mods[i + 1]
                         s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
                         t = bn.bias - bn.running_mean * s
@@ -294,8 +391,20 @@ class _MLP(nn.Module):
         return self._folded
 
     def forward(self, x):
+        if self.training and x.is_cuda:
+            # training: Linear by hipBLASLt, then BatchNorm1d + ReLU as ONE HIP pass each way (bn_kernels.hip)
+            mods = list(self.mlp)
+            i = 0
+            while i < len(mods):
+                if (i + 2 < len(mods) and isinstance(mods[i + 1], HipBatchNorm1d) and isinstance(mods[i + 2], nn.ReLU)):
+                    x = mods[i + 1](mods[i](x), relu=True)
+                    i += 3
+                else:
+                    x = mods[i](x)
+                    i += 1
+            return x
         if self.training or torch.is_grad_enabled() or not x.is_cuda or not self.fold_eval:
-            return self.mlp(x)                   # autograd / training: the plain nn.Sequential
+            return self.mlp(x)                   # autograd in eval mode / CPU: the plain nn.Sequential
         for wt, b, relu in self._fold():
             x = torch._addmm_activation(b, x, wt) if relu else torch.addmm(b, x, wt)
         return x

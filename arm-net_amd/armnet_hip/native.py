@@ -26,7 +26,8 @@ EXPORTS = (
     "armnet_fused_fwd_f32", "armnet_fused_fwd_from_rows_f32", "armnet_gather_scale_f32",
     "armnet_clamp_vals_f32", "armnet_entmax_f32", "armnet_shard_route_ws_bytes", "armnet_shard_route_ids",
     "armnet_fused_bwd_f32", "armnet_shard_route_unique_ws_bytes", "armnet_shard_route_unique_ids",
-    "armnet_fused_kernel_kind",
+    "armnet_fused_kernel_kind", "armnet_fused_bwd_bn_f32", "armnet_bn_stats_f32", "armnet_bn_finalize_f32",
+    "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
 )
 
 _lib = None
@@ -193,6 +194,70 @@ def fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values
                                       ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
                                       ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
                                       _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+
+
+def fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, z, dy, coefA, coefB, coefC,
+                 d_table, d_values, d_qfold):
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values), ("z", z), ("dy", dy),
+                 ("coefA", coefA), ("coefB", coefB), ("coefC", coefC),
+                 ("d_table", d_table), ("d_values", d_values), ("d_qfold", d_qfold)):
+        _dev_f32(t, n)
+    check(load().armnet_fused_bwd_bn_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                         ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                         ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dy),
+                                         _ptr(coefA), _ptr(coefB), _ptr(coefC),
+                                         _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+
+
+def _ncl(x):
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1], 1
+    if x.dim() == 3:
+        return x.shape[0], x.shape[1], x.shape[2]
+    raise ArmnetNativeError(f"BatchNorm1d input must be 2-D or 3-D, got {x.dim()}-D")
+
+
+def bn_forward_train(x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    """training-mode BatchNorm1d forward (+ optional ReLU): returns y, mean, rstd, scale, shift"""
+    _dev_f32(x, "x")
+    N, C, L = _ncl(x)
+    dev = x.device
+    buf = torch.zeros(6, C, device=dev, dtype=torch.float32)      # stats[2], mean, rstd, scale, shift
+    st = _stream()
+    lib = load()
+    check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
+    check(lib.armnet_bn_finalize_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(x), L, _ptr(weight), _ptr(bias),
+                                     ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
+                                     _ptr(running_var), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), st))
+    y = torch.empty_like(x)
+    check(lib.armnet_bn_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf[4]), _ptr(buf[5]), int(bool(relu)),
+                                  _ptr(y), st))
+    return y, buf[2], buf[3], buf[4], buf[5]
+
+
+def bn_backward_coef(x, dy, weight, mean, rstd, relu_scale=None, relu_shift=None):
+    """backward reductions of training-mode BatchNorm1d: returns d_weight, d_bias, coefA, coefB, coefC with
+    dx = coefA * dy + coefC * x + coefB (dy masked by the recomputed ReLU when relu_scale/shift are given)"""
+    _dev_f32(x, "x"); _dev_f32(dy, "dy")
+    N, C, L = _ncl(x)
+    buf = torch.zeros(7, C, device=x.device, dtype=torch.float32)   # sums[2], d_weight, d_bias, A, B, C
+    st = _stream()
+    lib = load()
+    check(lib.armnet_bn_bwd_reduce_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd),
+                                       _ptr(relu_scale), _ptr(relu_shift), _ptr(buf), st))
+    check(lib.armnet_bn_bwd_coef_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(weight), _ptr(mean), _ptr(rstd),
+                                     _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), _ptr(buf[6]), st))
+    return buf[2], buf[3], buf[4], buf[5], buf[6]
+
+
+def bn_backward_apply(x, dy, coefA, coefB, coefC, relu_scale=None, relu_shift=None):
+    N, C, L = _ncl(x)
+    dx = torch.empty_like(x)
+    check(load().armnet_bn_bwd_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(coefA), _ptr(coefB),
+                                         _ptr(coefC), _ptr(relu_scale), _ptr(relu_shift), _ptr(dx), _stream()))
+    return dx
 
 
 def shard_route_unique_ws_bytes(R, nfeat):

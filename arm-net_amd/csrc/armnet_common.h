@@ -248,7 +248,10 @@ struct BwdArgs {
     const float* values;    // [O,F]
     int O_all;              // neurons per sample in z / dz (0 = O): the MFMA kernel works on slices
     const float* z;         // [B,O_all,E] forward output (pre-BN neurons)
-    const float* dz;        // [B,O_all,E]
+    const float* dz;        // [B,O_all,E]  (with bn_a: the gradient of the BatchNorm OUTPUT, see bn_a)
+    const float* bn_a;      // optional [O] x3: dz = bn_a * dz_in + bn_c * z + bn_b (training BatchNorm backward folded in)
+    const float* bn_b;
+    const float* bn_c;
     float* d_table;         // [nfeat,E]  += (caller zero-initialises)
     float* d_values;        // [O,F]      +=
     float* d_qfold;         // [O,E]      +=

@@ -1,0 +1,258 @@
+// bn_kernels.hip — training-mode BatchNorm1d (forward statistics / apply, backward reductions / apply), gfx950.
+//
+// The reference normalises the exponential neurons with nn.BatchNorm1d(nhid) on a [B, nhid, nemb] tensor
+// (models/armnet_1h.py:65,85; models/armnet.py:67,88-89) and every MLP layer with nn.BatchNorm1d(nhid) on
+// [B, nhid] (models/layers.py:77).  In training these are batch-statistics layers: two HBM-bound reductions
+// and two HBM-bound elementwise passes per layer and step.  All four are one pass over x viewed as
+// [N, C, L] (L = 1 for 2-D input) with the same skeleton:
+//
+//   a thread owns inner positions i = c * L + l (coalesced across the wave), so its channel parameters are
+//   loaded once per position; a block owns a contiguous range of the N rows; reductions go thread -> LDS
+//   (one atomic per thread and position) -> one global atomic per channel and block.
+//
+// Variance uses sums shifted by k[c] = x[0, c, 0] (the exponential neurons have |mean| >> std: the plain
+// E[x^2] - E[x]^2 would cancel).  Optional fused ReLU (the MLP's BatchNorm1d -> ReLU, layers.py:77-78):
+// forward clamps, backward masks dy with (x * relu_scale[c] + relu_shift[c] > 0), recomputed from x.
+#include "armnet_common.h"
+
+namespace armnet {
+
+constexpr int BN_TPB = 256;
+constexpr int BN_UNROLL = 8;
+
+enum BnOp { BN_STATS = 0, BN_APPLY = 1, BN_BWD_REDUCE = 2, BN_BWD_APPLY = 3 };
+
+struct BnArgs {
+    int64_t N;
+    int C, L;
+    const float* x;
+    const float* dy;       // backward ops
+    const float* p0;       // apply: scale | bwd_reduce: mean | bwd_apply: coefA
+    const float* p1;       // apply: shift | bwd_reduce: rstd | bwd_apply: coefB
+    const float* p2;       //                                 bwd_apply: coefC
+    const float* rs;       // relu_scale (backward ops; null = no ReLU)
+    const float* rt;       // relu_shift
+    float* out;            // apply: y | bwd_apply: dx
+    float* sums;           // stats / bwd_reduce: [2C] accumulators (+=)
+    int relu;              // apply: clamp at 0
+    int rows_per_block;
+};
+
+template <int OP>
+__global__ void __launch_bounds__(BN_TPB) bn_pass_kernel(BnArgs a) {
+    extern __shared__ float acc[];                       // [2C] for the reducing ops
+    const int CL = a.C * a.L;
+    constexpr bool REDUCE = (OP == BN_STATS || OP == BN_BWD_REDUCE);
+    if constexpr (REDUCE) {
+        for (int i = threadIdx.x; i < 2 * a.C; i += BN_TPB) acc[i] = 0.f;
+        __syncthreads();
+    }
+    const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t n1 = n0 + a.rows_per_block;
+    if (n1 > a.N) n1 = a.N;
+    for (int i = threadIdx.x; i < CL; i += BN_TPB) {
+        const int c = i / a.L;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, r0 = 0.f, r1 = 0.f;
+        bool mask = false;
+        if constexpr (OP == BN_STATS) q0 = a.x[(size_t)c * a.L];                     // shift k[c] = x[0, c, 0]
+        if constexpr (OP == BN_APPLY) { q0 = a.p0[c]; q1 = a.p1[c]; }
+        if constexpr (OP == BN_BWD_REDUCE) { q0 = a.p0[c]; q1 = a.p1[c]; }
+        if constexpr (OP == BN_BWD_APPLY) { q0 = a.p0[c]; q1 = a.p1[c]; q2 = a.p2[c]; }
+        if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) {
+            mask = a.rs != nullptr;
+            if (mask) { r0 = a.rs[c]; r1 = a.rt[c]; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+        const float* xp = a.x + (size_t)n0 * CL + i;
+        const float* gp = (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) ? a.dy + (size_t)n0 * CL + i : nullptr;
+        float* op = (OP == BN_APPLY || OP == BN_BWD_APPLY) ? a.out + (size_t)n0 * CL + i : nullptr;
+        int64_t n = n0;
+        for (; n + BN_UNROLL <= n1; n += BN_UNROLL) {
+            float xv[BN_UNROLL], gv[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                xv[u] = xp[(size_t)u * CL];
+                if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gv[u] = gp[(size_t)u * CL];
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                if constexpr (OP == BN_STATS) {
+                    const float d = xv[u] - q0;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                } else if constexpr (OP == BN_APPLY) {
+                    float y = fmaf(xv[u], q0, q1);
+                    if (a.relu) y = y > 0.f ? y : (y != y ? y : 0.f);               // NaN stays NaN like torch.relu
+                    op[(size_t)u * CL] = y;
+                } else {
+                    float g = gv[u];
+                    if (mask) g = fmaf(xv[u], r0, r1) > 0.f ? g : 0.f;
+                    if constexpr (OP == BN_BWD_REDUCE) {
+                        s1 += g;
+                        s2 = fmaf(g, (xv[u] - q0) * q1, s2);        // dy * xhat
+                    } else {
+                        op[(size_t)u * CL] = fmaf(q0, g, fmaf(q2, xv[u], q1));
+                    }
+                }
+            }
+            xp += (size_t)BN_UNROLL * CL;
+            if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gp += (size_t)BN_UNROLL * CL;
+            if constexpr (OP == BN_APPLY || OP == BN_BWD_APPLY) op += (size_t)BN_UNROLL * CL;
+        }
+        for (; n < n1; ++n) {
+            const float xv = *xp;
+            if constexpr (OP == BN_STATS) {
+                const float d = xv - q0;
+                s1 += d;
+                s2 = fmaf(d, d, s2);
+            } else if constexpr (OP == BN_APPLY) {
+                float y = fmaf(xv, q0, q1);
+                if (a.relu) y = y > 0.f ? y : (y != y ? y : 0.f);
+                *op = y;
+            } else {
+                float g = *gp;
+                if (mask) g = fmaf(xv, r0, r1) > 0.f ? g : 0.f;
+                if constexpr (OP == BN_BWD_REDUCE) {
+                    s1 += g;
+                    s2 = fmaf(g, (xv - q0) * q1, s2);
+                } else {
+                    *op = fmaf(q0, g, fmaf(q2, xv, q1));
+                }
+            }
+            xp += CL;
+            if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gp += CL;
+            if constexpr (OP == BN_APPLY || OP == BN_BWD_APPLY) op += CL;
+        }
+        if constexpr (REDUCE) {
+            atomicAdd(&acc[c], s1);
+            atomicAdd(&acc[a.C + c], s2);
+        }
+    }
+    if constexpr (REDUCE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * a.C; i += BN_TPB) unsafeAtomicAdd(a.sums + i, acc[i]);
+    }
+}
+
+template <int OP>
+static int launch_bn_pass(BnArgs a, hipStream_t st) {
+    if (a.N == 0) return ARMNET_OK;
+    // ~8 blocks per CU; at least BN_UNROLL rows per block so the unrolled loop is the common path
+    int64_t rpb = (a.N + 2047) / 2048;
+    if (rpb < BN_UNROLL) rpb = BN_UNROLL;
+    a.rows_per_block = (int)rpb;
+    const int64_t grid = (a.N + rpb - 1) / rpb;
+    const size_t lds = (OP == BN_STATS || OP == BN_BWD_REDUCE) ? (size_t)2 * a.C * sizeof(float) : 0;
+    if (lds > 64 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    bn_pass_kernel<OP><<<(int)grid, BN_TPB, lds, st>>>(a);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+// per-channel epilogue of the forward statistics (torch.nn.functional.batch_norm, training = True)
+__global__ void bn_finalize_kernel(int C, float count, const float* stats, const float* x, int L,
+                                   const float* weight, const float* bias, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean, float* rstd,
+                                   float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float k = x[(size_t)c * L];
+    const float m1 = stats[c] / count;
+    float var = stats[C + c] / count - m1 * m1;          // biased (what normalises the batch)
+    var = var > 0.f ? var : (var != var ? var : 0.f);
+    const float mu = k + m1;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float w = weight ? weight[c] : 1.0f, b = bias ? bias[c] : 0.f;
+    mean[c] = mu;
+    rstd[c] = r;
+    scale[c] = w * r;
+    shift[c] = b - mu * (w * r);
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+        const float unbiased = count > 1.0f ? var * (count / (count - 1.0f)) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// per-channel epilogue of the backward reductions:  dx = A * dy + Cc * x + Bc
+//   dbeta = sum dy, dgamma = sum dy * xhat;  dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat))
+__global__ void bn_bwd_coef_kernel(int C, float count, const float* sums, const float* weight, const float* mean,
+                                   const float* rstd, float* d_weight, float* d_bias, float* coefA, float* coefB,
+                                   float* coefC) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float db = sums[c], dg = sums[C + c];
+    if (d_bias) d_bias[c] = db;
+    if (d_weight) d_weight[c] = dg;
+    const float w = weight ? weight[c] : 1.0f;
+    const float A = w * rstd[c];
+    const float Cc = -A * rstd[c] * (dg / count);
+    coefA[c] = A;
+    coefC[c] = Cc;
+    coefB[c] = -A * (db / count) - Cc * mean[c];
+}
+
+}  // namespace armnet
+
+using namespace armnet;
+
+static bool bn_shape_ok(int64_t N, int C, int L) { return N >= 0 && C > 0 && L > 0 && (int64_t)C * L < ((int64_t)1 << 30); }
+
+extern "C" int armnet_bn_stats_f32(int64_t N, int C, int L, const float* x, float* stats, void* stream) {
+    if (!bn_shape_ok(N, C, L) || !x || !stats) return ARMNET_ERR_BAD_ARG;
+    BnArgs a{};
+    a.N = N; a.C = C; a.L = L; a.x = x; a.sums = stats;
+    return launch_bn_pass<BN_STATS>(a, (hipStream_t)stream);
+}
+
+extern "C" int armnet_bn_finalize_f32(int C, int64_t count, const float* stats, const float* x, int L,
+                                      const float* weight, const float* bias, float eps, float momentum,
+                                      float* running_mean, float* running_var, float* mean, float* rstd,
+                                      float* scale, float* shift, void* stream) {
+    if (C <= 0 || count <= 0 || L <= 0 || !stats || !x || !mean || !rstd || !scale || !shift) return ARMNET_ERR_BAD_ARG;
+    bn_finalize_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, (float)count, stats, x, L, weight, bias, eps,
+                                                                         momentum, running_mean, running_var, mean,
+                                                                         rstd, scale, shift);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+extern "C" int armnet_bn_apply_f32(int64_t N, int C, int L, const float* x, const float* scale, const float* shift,
+                                   int relu, float* y, void* stream) {
+    if (!bn_shape_ok(N, C, L) || !x || !scale || !shift || !y) return ARMNET_ERR_BAD_ARG;
+    BnArgs a{};
+    a.N = N; a.C = C; a.L = L; a.x = x; a.p0 = scale; a.p1 = shift; a.relu = relu; a.out = y;
+    return launch_bn_pass<BN_APPLY>(a, (hipStream_t)stream);
+}
+
+extern "C" int armnet_bn_bwd_reduce_f32(int64_t N, int C, int L, const float* x, const float* dy, const float* mean,
+                                        const float* rstd, const float* relu_scale, const float* relu_shift,
+                                        float* sums, void* stream) {
+    if (!bn_shape_ok(N, C, L) || !x || !dy || !mean || !rstd || !sums) return ARMNET_ERR_BAD_ARG;
+    if ((relu_scale == nullptr) != (relu_shift == nullptr)) return ARMNET_ERR_BAD_ARG;
+    BnArgs a{};
+    a.N = N; a.C = C; a.L = L; a.x = x; a.dy = dy; a.p0 = mean; a.p1 = rstd;
+    a.rs = relu_scale; a.rt = relu_shift; a.sums = sums;
+    return launch_bn_pass<BN_BWD_REDUCE>(a, (hipStream_t)stream);
+}
+
+extern "C" int armnet_bn_bwd_coef_f32(int C, int64_t count, const float* sums, const float* weight, const float* mean,
+                                      const float* rstd, float* d_weight, float* d_bias, float* coefA, float* coefB,
+                                      float* coefC, void* stream) {
+    if (C <= 0 || count <= 0 || !sums || !mean || !rstd || !coefA || !coefB || !coefC) return ARMNET_ERR_BAD_ARG;
+    bn_bwd_coef_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, (float)count, sums, weight, mean, rstd,
+                                                                         d_weight, d_bias, coefA, coefB, coefC);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+extern "C" int armnet_bn_bwd_apply_f32(int64_t N, int C, int L, const float* x, const float* dy, const float* coefA,
+                                       const float* coefB, const float* coefC, const float* relu_scale,
+                                       const float* relu_shift, float* dx, void* stream) {
+    if (!bn_shape_ok(N, C, L) || !x || !dy || !coefA || !coefB || !coefC || !dx) return ARMNET_ERR_BAD_ARG;
+    if ((relu_scale == nullptr) != (relu_shift == nullptr)) return ARMNET_ERR_BAD_ARG;
+    BnArgs a{};
+    a.N = N; a.C = C; a.L = L; a.x = x; a.dy = dy; a.p0 = coefA; a.p1 = coefB; a.p2 = coefC;
+    a.rs = relu_scale; a.rt = relu_shift; a.out = dx;
+    return launch_bn_pass<BN_BWD_APPLY>(a, (hipStream_t)stream);
+}

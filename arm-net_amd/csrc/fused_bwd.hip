@@ -68,7 +68,11 @@ __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
             }
             sparse_map_row(pw, CS, F, a.cfg);                         // p (same solver as the forward)
             const size_t zo = ((size_t)(b0 + s) * O + o) * E;
-            for (int e = 0; e < E; ++e) dsr[e] = a.dz[zo + e] * a.z[zo + e];
+            const float cA = a.bn_a ? a.bn_a[o] : 1.0f, cB = a.bn_a ? a.bn_b[o] : 0.f, cC = a.bn_a ? a.bn_c[o] : 0.f;
+            for (int e = 0; e < E; ++e) {
+                const float zv = a.z[zo + e];
+                dsr[e] = fmaf(cA, a.dz[zo + e], fmaf(cC, zv, cB)) * zv;
+            }
             // dW, dvalues, dp; entmax / softmax Jacobian-vector product
             float s1 = 0.f, s2 = 0.f;
             for (int f = 0; f < F; ++f) {
@@ -168,11 +172,10 @@ int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
 
 using namespace armnet;
 
-extern "C" int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
-                                    const void* ids, int id_type, const float* vals, const float* table,
-                                    int64_t nfeat, const float* q_fold, const float* values, const float* z,
-                                    const float* dz, float* d_table, float* d_values, float* d_qfold,
-                                    void* stream) {
+static int fused_bwd_impl(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags, const void* ids,
+                          int id_type, const float* vals, const float* table, int64_t nfeat, const float* q_fold,
+                          const float* values, const float* z, const float* dz, const float* bn_a, const float* bn_b,
+                          const float* bn_c, float* d_table, float* d_values, float* d_qfold, void* stream) {
     if (B < 0 || F <= 0 || E <= 0 || O <= 0 || n_iter < 0 || nfeat <= 0) return ARMNET_ERR_BAD_ARG;
     if (!ids || !vals || !table || !q_fold || !values || !z || !dz || !d_table || !d_values || !d_qfold)
         return ARMNET_ERR_BAD_ARG;
@@ -183,9 +186,29 @@ extern "C" int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha,
     a.B = B; a.F = F; a.E = E; a.O = O;
     a.ids = ids; a.id_type = id_type; a.vals = vals; a.table = table; a.nfeat = nfeat;
     a.q_fold = q_fold; a.values = values; a.z = z; a.dz = dz;
+    a.bn_a = bn_a; a.bn_b = bn_b; a.bn_c = bn_c;
     a.d_table = d_table; a.d_values = d_values; a.d_qfold = d_qfold;
     a.cfg = make_sparse_cfg(alpha, n_iter, F, 1, flags);
     a.alpha = alpha;
     a.flags = flags;
     return launch_fused_bwd(a, (hipStream_t)stream);
+}
+
+extern "C" int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                                    const void* ids, int id_type, const float* vals, const float* table,
+                                    int64_t nfeat, const float* q_fold, const float* values, const float* z,
+                                    const float* dz, float* d_table, float* d_values, float* d_qfold,
+                                    void* stream) {
+    return fused_bwd_impl(B, F, E, O, alpha, n_iter, flags, ids, id_type, vals, table, nfeat, q_fold, values, z, dz,
+                          nullptr, nullptr, nullptr, d_table, d_values, d_qfold, stream);
+}
+
+extern "C" int armnet_fused_bwd_bn_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                                       const void* ids, int id_type, const float* vals, const float* table,
+                                       int64_t nfeat, const float* q_fold, const float* values, const float* z,
+                                       const float* dy, const float* coefA, const float* coefB, const float* coefC,
+                                       float* d_table, float* d_values, float* d_qfold, void* stream) {
+    if (!coefA || !coefB || !coefC) return ARMNET_ERR_BAD_ARG;
+    return fused_bwd_impl(B, F, E, O, alpha, n_iter, flags, ids, id_type, vals, table, nfeat, q_fold, values, z, dy,
+                          coefA, coefB, coefC, d_table, d_values, d_qfold, stream);
 }

@@ -27,6 +27,7 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
         s.values = a.values + (size_t)o0 * a.F;
         s.z = a.z + (size_t)o0 * a.E;
         s.dz = a.dz + (size_t)o0 * a.E;
+        if (a.bn_a) { s.bn_a = a.bn_a + o0; s.bn_b = a.bn_b + o0; s.bn_c = a.bn_c + o0; }
         s.d_values = a.d_values + (size_t)o0 * a.F;
         s.d_qfold = a.d_qfold + (size_t)o0 * a.E;
         int rc;

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     float* qfl = p_vv + NT * NP * 64 * 2;     // [OP][ES]            q_fold, plain (B operand of MFMA #5)
     float* acc_dv = qfl + OP * ES;            // [OP][FP]
     float* acc_dq = acc_dv + OP * FP;         // [OP][E]
+    float* p_cf = acc_dq + OP * E;            // [OP] f32x4 {A, B, C, -}: dz = A * dz_in + C * z + B (BatchNorm backward)
 
     const int Bi = (int)a.B;
     const int nwaves = (int)gridDim.x * 4;
@@ -139,6 +140,10 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         qfl[i] = (o < O && e < Er) ? a.q_fold[(size_t)o * Er + e] : 0.f;
     }
     for (int i = threadIdx.x; i < OP * (FP + E); i += 256) acc_dv[i] = 0.f;     // acc_dv and acc_dq are contiguous
+    for (int i = threadIdx.x; i < OP; i += 256) {
+        const bool on = a.bn_a != nullptr && i < O;
+        *reinterpret_cast<f32x4*>(p_cf + 4 * i) = f32x4{on ? a.bn_a[i] : 1.0f, on ? a.bn_b[i] : 0.f, on ? a.bn_c[i] : 0.f, 0.f};
+    }
     __syncthreads();
 
     const float am1 = a.cfg.am1;
@@ -159,42 +164,109 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         for (int eb = 0; eb < EB; ++eb) dqacc[n][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int b = (int)blockIdx.x * 4 + wave; b < Bi; b += nwaves) {
+    // ---- software pipeline over the wave's samples: rows of the next sample and ids / values of the one after are
+    //      in flight while the current one computes; dz / z of the next pass (or of the next sample's first pass)
+    //      are fetched one pass ahead.  Samples past the end re-read the last one (never used).
+    uint32_t idC[NI], idN[NI];
+    float vC[NI], vN[NI];
+    RowT rwC[NI];
+    f32x4 zN[EB], dN[EB];
+    auto fetch_ids = [&](int bb, uint32_t (&idr)[NI], float (&vr)[NI]) {
+        const size_t e0 = (size_t)(bb < Bi ? bb : Bi - 1) * F;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            uint32_t lo, hi = 0u;
+            if constexpr (SRC == 0) {
+                const uint2 w = reinterpret_cast<const uint2*>(a.ids)[e0 + fld[n]];
+                lo = w.x;
+                hi = w.y;
+            } else {
+                lo = reinterpret_cast<const uint32_t*>(a.ids)[e0 + fld[n]];
+            }
+            idr[n] = (hi != 0u || lo > id_max) ? 0u : lo;          // the forward already raised on bad ids
+            if (dbg_hot_rows) idr[n] &= 1023u;
+            vr[n] = a.vals[e0 + fld[n]];
+        }
+    };
+    auto fetch_rows = [&]() {
+#pragma unroll
+        for (int n = 0; n < NI; ++n) rwC[n] = *reinterpret_cast<const RowT*>(row_base + (size_t)idC[n] * row_bytes);
+    };
+    auto fetch_zd = [&](int bb, int nt) {
+        const int o = 16 * nt + c;
+        const size_t zo = ((size_t)(bb < Bi ? bb : Bi - 1) * O_all + o) * (size_t)Er + 4 * g;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+            zN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < O) {
+                if (full_rows) {
+                    zN[eb] = *reinterpret_cast<const f32x4*>(a.z + zo + 16 * eb);
+                    dN[eb] = *reinterpret_cast<const f32x4*>(a.dz + zo + 16 * eb);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * eb + 4 * g + r < Er) {
+                            zN[eb][r] = a.z[zo + 16 * eb + r];
+                            dN[eb][r] = a.dz[zo + 16 * eb + r];
+                        }
+                }
+            }
+        }
+    };
+    const int b_first = (int)blockIdx.x * 4 + wave;
+    const int npass = dbg_one_pass ? 1 : NT;
+    // prefetch depth by register budget: 2 = rows of the next sample + ids of the one after + dz/z one pass ahead
+    // (nemb <= 16), 1 = ids of the next sample + dz/z one pass ahead (nemb <= 32), 0 = nothing carried (nemb = 64)
+    constexpr int PF = E <= 16 ? 2 : (E <= 32 && NQ <= 8) ? 1 : 0;
+    if (b_first < Bi) {
+        if constexpr (PF == 2) {
+            fetch_ids(b_first, idC, vC);
+            fetch_zd(b_first, 0);
+            fetch_rows();
+            fetch_ids(b_first + nwaves, idN, vN);
+        } else if constexpr (PF == 1) {
+            fetch_ids(b_first, idN, vN);
+            fetch_zd(b_first, 0);
+        }
+    }
+
+    for (int b = b_first; b < Bi; b += nwaves) {
         // ---- stage the sample's rows (scaled) into the wave's tile; remember id / value per tile row ----
         wave_lds_fence();
-        {
-            uint32_t idr[NI];
-            float vr[NI];
-            RowT rw[NI];
-            const size_t e0 = (size_t)b * F;
+        if constexpr (PF == 1) {
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                uint32_t lo, hi = 0u;
-                if constexpr (SRC == 0) {
-                    const uint2 w = reinterpret_cast<const uint2*>(a.ids)[e0 + fld[n]];
-                    lo = w.x;
-                    hi = w.y;
-                } else {
-                    lo = reinterpret_cast<const uint32_t*>(a.ids)[e0 + fld[n]];
-                }
-                idr[n] = (hi != 0u || lo > id_max) ? 0u : lo;      // the forward already raised on bad ids
-                if (dbg_hot_rows) idr[n] &= 1023u;
-                vr[n] = a.vals[e0 + fld[n]];
+                idC[n] = idN[n];
+                vC[n] = vN[n];
             }
+            fetch_rows();
+            fetch_ids(b + nwaves, idN, vN);
+        } else if constexpr (PF == 0) {
+            fetch_ids(b, idC, vC);
+            fetch_rows();
+        }
 #pragma unroll
-            for (int n = 0; n < NI; ++n) rw[n] = *reinterpret_cast<const RowT*>(row_base + (size_t)idr[n] * row_bytes);
+        for (int n = 0; n < NI; ++n) {
+            const int row = n * RPI + lane / CH;
+            *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = rwC[n] * vC[n];
+            if (chunk == 0) {
+                idl[row] = pad[n] ? 0xffffffffu : idC[n];
+                vll[row] = vC[n];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NZ; ++m)
+            if (zoff[m] >= 0) *reinterpret_cast<f32x4*>(xt + zoff[m]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PF == 2) {
+            // next sample's rows (its ids arrived during the previous sample), ids / values of the one after
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                const int row = n * RPI + lane / CH;
-                *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = rw[n] * vr[n];
-                if (chunk == 0) {
-                    idl[row] = pad[n] ? 0xffffffffu : idr[n];
-                    vll[row] = vr[n];
-                }
+                idC[n] = idN[n];
+                vC[n] = vN[n];
             }
-#pragma unroll
-            for (int m = 0; m < NZ; ++m)
-                if (zoff[m] >= 0) *reinterpret_cast<f32x4*>(xt + zoff[m]) = f32x4{0.f, 0.f, 0.f, 0.f};
+            fetch_rows();
+            fetch_ids(b + 2 * nwaves, idN, vN);
         }
         wave_lds_fence();
 
@@ -206,30 +278,23 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 
 #pragma unroll
         for (int nt = 0; nt < kBwdNT; ++nt) {
-            if (nt >= (dbg_one_pass ? 1 : NT)) break;                   // wave-uniform
-            // ---- ds = dz * z of this lane's neuron: the B operand of MFMA #3 (issue the loads first) --------
-            const int o = 16 * nt + c;
+            if (nt >= npass) break;                                      // wave-uniform
+            // ---- ds = dz * z of this lane's neuron: the B operand of MFMA #3 (fetched one pass ahead) ----------
             f32x4 ds4[EB];
+            if constexpr (PF == 0) fetch_zd(b, nt);
             {
-                const size_t zo = ((size_t)b * O_all + o) * (size_t)Er + 4 * g;
+                const f32x4 cf = *reinterpret_cast<const f32x4*>(p_cf + 4 * (16 * nt + c));
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
-                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
-                    if (o < O) {
-                        if (full_rows) {
-                            z4 = *reinterpret_cast<const f32x4*>(a.z + zo + 16 * eb);
-                            d4 = *reinterpret_cast<const f32x4*>(a.dz + zo + 16 * eb);
-                        } else {
+                    f32x4 dzv;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (16 * eb + 4 * g + r < Er) {
-                                    z4[r] = a.z[zo + 16 * eb + r];
-                                    d4[r] = a.dz[zo + 16 * eb + r];
-                                }
-                        }
-                    }
-                    ds4[eb] = z4 * d4;
+                    for (int r = 0; r < 4; ++r) dzv[r] = fmaf(cf[0], dN[eb][r], fmaf(cf[2], zN[eb][r], cf[1]));
+                    ds4[eb] = dzv * zN[eb];     // padding lanes (neuron >= O, e >= nemb) hold z = 0: ds = 0 whatever the shift
                 }
+            }
+            if constexpr (PF >= 1) {
+                if (nt + 1 < npass) fetch_zd(b, nt + 1);
+                else fetch_zd(b + nwaves, 0);
             }
             // ---- MFMA #1: gates -------------------------------------------------------------------------
             f32x4 c1[NTILE];
@@ -522,9 +587,10 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     constexpr int NTILE = (NQ + 3) / 4, ROWS = NTILE * 16;
     constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 2 * 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
     const int NT = (a.O + 15) / 16, OP = NT * 16;
-    const size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
-                        (size_t)OP * (E + 4) + (size_t)OP * (4 * NQ) + (size_t)OP * E) * sizeof(float);
+    size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
+                  (size_t)OP * (E + 4) + (size_t)OP * (4 * NQ) + (size_t)OP * E + (size_t)OP * 4) * sizeof(float);
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > 2) per_cu = 2;
     const int64_t blocks = (a.B + 3) / 4;

@@ -7,7 +7,7 @@ namespace armnet {
 bool fused_mfma_supports(int F, int E, int O) {
     if (E < 2 || E > 64 || (E & 1) || O < 1 || O > 1024 || F < 1 || F > 48) return false;
     const int nq = (((F + 3) / 4) + 1) & ~1;
-    if (E > 32 && (E % 4 != 0 || nq < 4)) return false;   // the nemb=64 family has 16-byte chunks only
+    if (E > 32 && E % 4 != 0) return false;               // the nemb=64 family has 16-byte chunks only
     if (E > 16 && E <= 32 && E % 4 != 0) return false;    // 8-byte chunks are instantiated for nemb <= 16
     // LDS of one block (same formula as launch_one): 4 wave tiles + the lane-ready parameters of one slice
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;

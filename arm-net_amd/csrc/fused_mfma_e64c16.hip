@@ -5,6 +5,7 @@ namespace armnet {
 
 int launch_mfma_e64_c16(const FusedArgs& a, int nq, hipStream_t st) {
     switch (nq) {
+        case 2: return launch_src<64, 2, 16, true>(a, st);
         case 4: return launch_src<64, 4, 16, true>(a, st);
         case 6: return launch_src<64, 6, 16, true>(a, st);
         case 8: return launch_src<64, 8, 16, true>(a, st);

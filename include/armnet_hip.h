@@ -151,6 +151,52 @@ int armnet_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter
                          float* d_table, float* d_values, float* d_qfold, void* stream);
 
 /*
+ * The same backward with the training-mode BatchNorm1d that follows the block (armnet_1h.py:85 / armnet.py:88-89)
+ * folded in: `dy` is the gradient of the BatchNorm OUTPUT and the kernel forms
+ *     dz = coefA[o] * dy + coefC[o] * z + coefB[o]
+ * on the fly (coefficients from armnet_bn_bwd_coef_f32), so the gradient of the pre-BN neurons is never
+ * written to memory.
+ */
+int armnet_fused_bwd_bn_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                            const void* ids, int id_type, const float* vals, const float* table, int64_t nfeat,
+                            const float* q_fold, const float* values, const float* z, const float* dy,
+                            const float* coefA, const float* coefB, const float* coefC,
+                            float* d_table, float* d_values, float* d_qfold, void* stream);
+
+/*
+ * Training-mode torch.nn.BatchNorm1d (armnet_1h.py:65,85, armnet.py:67,88-89 on [B, nhid, nemb]; layers.py:77
+ * on [B, nhid]) as HBM-bound passes over x viewed as [N, C, L] (L = 1 for 2-D input).  Forward:
+ *   armnet_bn_stats_f32     stats[c] += sum (x - k_c), stats[C + c] += sum (x - k_c)^2 with k_c = x[0, c, 0]
+ *                           (caller zero-initialises stats[2C]; shifted sums: no cancellation when |mean| >> std)
+ *   armnet_bn_finalize_f32  per channel: mean, rstd = 1/sqrt(biased var + eps), scale = weight * rstd,
+ *                           shift = bias - mean * scale; running_mean / running_var (unbiased) updated in place
+ *                           with `momentum` when non-NULL (count = N * L; weight / bias may be NULL)
+ *   armnet_bn_apply_f32     y = x * scale[c] + shift[c], optionally followed by ReLU (layers.py:78)
+ * Backward (dy = gradient of y; with relu_scale/relu_shift = the forward's scale/shift the ReLU mask
+ * x * scale + shift > 0 is recomputed and applied to dy):
+ *   armnet_bn_bwd_reduce_f32  sums[c] += sum dy, sums[C + c] += sum dy * xhat   (caller zero-initialises)
+ *   armnet_bn_bwd_coef_f32    d_bias = sums[:C], d_weight = sums[C:], and the coefficients of
+ *                             dx = coefA * dy + coefC * x + coefB
+ *   armnet_bn_bwd_apply_f32   dx elementwise (for the block's BatchNorm use armnet_fused_bwd_bn_f32 instead)
+ */
+int armnet_bn_stats_f32(int64_t N, int C, int L, const float* x, float* stats, void* stream);
+int armnet_bn_finalize_f32(int C, int64_t count, const float* stats, const float* x, int L,
+                           const float* weight, const float* bias, float eps, float momentum,
+                           float* running_mean, float* running_var,
+                           float* mean, float* rstd, float* scale, float* shift, void* stream);
+int armnet_bn_apply_f32(int64_t N, int C, int L, const float* x, const float* scale, const float* shift,
+                        int relu, float* y, void* stream);
+int armnet_bn_bwd_reduce_f32(int64_t N, int C, int L, const float* x, const float* dy, const float* mean,
+                             const float* rstd, const float* relu_scale, const float* relu_shift,
+                             float* sums, void* stream);
+int armnet_bn_bwd_coef_f32(int C, int64_t count, const float* sums, const float* weight, const float* mean,
+                           const float* rstd, float* d_weight, float* d_bias,
+                           float* coefA, float* coefB, float* coefC, void* stream);
+int armnet_bn_bwd_apply_f32(int64_t N, int C, int L, const float* x, const float* dy, const float* coefA,
+                            const float* coefB, const float* coefC, const float* relu_scale,
+                            const float* relu_shift, float* dx, void* stream);
+
+/*
  * Routing step of the row-sharded embedding lookup (multi-GPU; no reference counterpart — the
  * reference is single-device).  Rank r of R owns table rows {i : i % R == r},
  * stored at local index i / R.  For n ids: counts[r] = ids owned by r; send_local[p] = local row

@@ -253,7 +253,7 @@ def _random_model(variant, F, nfeat, E, alpha, H, K, seed):
 SHAPE_SWEEP = [
     ("1h", 1, 2, 1, 1, 2.0), ("1h", 2, 4, 3, 1, 1.5), ("1h", 3, 10, 128, 1, 2.0), ("1h", 5, 6, 17, 1, 1.7),
     ("1h", 8, 16, 16, 1, 2.0), ("1h", 9, 14, 33, 1, 1.0), ("mh", 12, 10, 20, 3, 2.0), ("1h", 16, 16, 48, 1, 1.5),
-    ("1h", 17, 18, 5, 1, 2.0), ("mh", 21, 20, 9, 2, 1.7), ("1h", 24, 24, 40, 1, 2.0), ("1h", 25, 28, 31, 1, 1.5),
+    ("1h", 17, 20, 5, 1, 2.0), ("mh", 21, 20, 9, 2, 1.7), ("1h", 24, 24, 40, 1, 2.0), ("1h", 25, 28, 31, 1, 1.5),
     ("1h", 31, 32, 64, 1, 1.0), ("mh", 33, 10, 64, 4, 2.0), ("1h", 39, 10, 128, 1, 2.0), ("1h", 40, 12, 100, 1, 1.7),
     ("mh", 43, 10, 64, 8, 1.5), ("1h", 47, 8, 19, 1, 2.0), ("1h", 48, 16, 300, 1, 2.0), ("1h", 7, 36, 12, 1, 2.0),
     ("1h", 13, 48, 20, 1, 1.5), ("1h", 22, 64, 32, 1, 2.0), ("mh", 30, 40, 10, 2, 1.7), ("1h", 44, 64, 24, 1, 1.0),

@@ -78,7 +78,7 @@ def test_a_few_adam_steps_reduce_the_loss():
 # (nfield, nemb, neurons, alpha): every staging family and solver mode of the matrix-core backward, neuron counts that
 # need padding and more than one 64-neuron slice
 BWD_SWEEP = [(1, 2, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5), (9, 14, 33, 1.0), (13, 8, 16, 2.0),
-             (17, 18, 5, 2.0), (22, 32, 32, 2.0), (22, 10, 64, 1.5), (25, 28, 70, 1.5), (31, 32, 64, 1.0),
+             (17, 20, 5, 2.0), (22, 32, 32, 2.0), (22, 10, 64, 1.5), (25, 28, 70, 1.5), (31, 32, 64, 1.0),
              (39, 16, 32, 2.0), (39, 16, 32, 1.5), (39, 16, 32, 1.7), (39, 16, 32, 1.0), (39, 10, 128, 2.0),
              (43, 10, 96, 1.7), (47, 8, 19, 2.0), (48, 64, 24, 2.0), (39, 64, 32, 1.5), (30, 40, 20, 1.7), (6, 60, 7, 1.0)]
 
@@ -112,3 +112,36 @@ def test_mfma_backward_agrees_with_the_generic_backward(F, E, O, alpha):
         scale = max(float(b.abs().max()), 1e-12)
         assert float((a - b).abs().max()) / scale <= 2e-5, name
         assert float((c - b).abs().max()) / scale <= 2e-5, name + " (int32 ids)"
+
+
+@pytest.mark.parametrize("shape,relu", [((64, 32, 16), False), ((37, 7, 10), False), ((1000, 256), True),
+                                        ((33, 20), True), ((2, 5), False), ((4097, 12, 3), True)])
+def test_hip_batchnorm_training_matches_float64_batchnorm(shape, relu):
+    """HipBatchNorm1d (bn_kernels.hip) in training mode against torch.nn.BatchNorm1d (+ ReLU) evaluated in float64
+    on the same data: output, running statistics, and the gradients of input / weight / bias.  The channel means
+    are far from 0 relative to the spread, like the exponential neurons: the case the shifted sums are for (the
+    fp32 torch / MIOpen layer is itself ~1e-4 off the float64 result here, so it cannot be the yardstick)."""
+    from armnet_hip.modules import HipBatchNorm1d
+    g = torch.Generator().manual_seed(sum(shape) + int(relu))
+    C = shape[1]
+    x0 = (torch.randn(*shape, generator=g) * 0.05 + torch.linspace(-3, 3, C).view(1, C, *([1] * (len(shape) - 2)))).to(DEV)
+    w0, b0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(*shape, generator=g).to(DEV)
+    outs = []
+    for cls, dt in ((torch.nn.BatchNorm1d, torch.float64), (HipBatchNorm1d, torch.float32)):
+        bn = cls(C).to(DEV).to(dt).train()
+        with torch.no_grad():
+            bn.weight.copy_(w0); bn.bias.copy_(b0)
+            bn.running_mean.fill_(0.25); bn.running_var.fill_(2.0)
+        x = x0.clone().to(dt).requires_grad_(True)
+        y = bn(x, relu=True) if (relu and cls is HipBatchNorm1d) else (torch.relu(bn(x)) if relu else bn(x))
+        y.backward(dy.to(dt))
+        outs.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                     int(bn.num_batches_tracked)))
+    ref, got = outs
+    names = ("y", "dx", "d_weight", "d_bias", "running_mean", "running_var")
+    for n, a, b in zip(names, got[:6], ref[:6]):
+        scale = max(float(b.abs().max()), 1e-6)
+        # ReLU: an element whose pre-activation is within rounding of 0 may flip; none of these seeds has one
+        assert float((a.double() - b).abs().max()) / scale <= 2e-5, n
+    assert got[6] == ref[6] == 1
