@@ -143,6 +143,32 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx, d_w, d_b, None, None, None, None, None
 
 
+class _LinearSplitKFn(torch.autograd.Function):
+    """nn.Linear whose weight gradient dW = dy^T x is computed split-K: with B = 65 536 rows and a [256, 512]
+    result the plain GEMM has 16 output tiles for 256 CUs (hipBLASLt: 0.6 ms = 28 TFLOP/s); as a batched GEMM
+    over S row-chunks plus a sum it fills the chip.  Same fp32 products, a different (pairwise-like) summation
+    order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B = x.shape[0]
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        S = 1
+        while S < 64 and B % (2 * S) == 0 and B // (2 * S) >= 1024:
+            S *= 2
+        if S > 1:
+            dw = torch.bmm(dy.view(S, B // S, -1).transpose(1, 2), x.view(S, B // S, -1)).sum(0)
+        else:
+            dw = dy.t() @ x
+        return dx, dw, dy.sum(0)
+
+
 class HipBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters, buffers and state_dict keys) whose TRAINING forward/backward on the GPU
     run as the HBM-bound HIP passes of bn_kernels.hip; eval mode and anything unusual (no affine, no running
@@ -352,6 +378,57 @@ class GraphedForward:
         return self.out
 
 
+class GraphedTrainStep:
+    """hipGraph-captured training step (forward, loss, backward, optimizer step) of one ARM-Net module at a fixed
+    batch shape.  At the reference's default batch size (train.py: 4096) a step is ~60 short kernels and the host
+    (Python, allocator, launches) takes longer than the GPU; replaying one graph removes that.
+
+        step = GraphedTrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True), loss_fn, ids, vals, y)
+        loss = step(ids, vals, y)          # static loss tensor, overwritten by the next call
+
+    The optimizer must be capture-safe (torch: ``capturable=True``).  Out-of-range ids are not reported inside a
+    capture (they read row 0); validate the data once outside.  x['value'] is clamped in the static copy and
+    mirrored back to the caller's tensor like the eager step."""
+
+    def __init__(self, model, optimizer, loss_fn, ids, vals, y, warmup=3):
+        if not model.training:
+            raise RuntimeError("GraphedTrainStep captures the training path: call model.train() first")
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.ids, self.vals, self.y = ids.clone(), vals.clone(), y.clone()
+        self._check = model.check_ids
+        model.check_ids = False                     # no host sync inside a capture
+        if hasattr(model, "deep_embedding"):
+            model.deep_embedding.check_ids = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager(zero=False)
+
+    def _eager(self, zero=True):
+        if zero:
+            self.opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model({"id": self.ids, "value": self.vals}), self.y)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, ids, vals, y):
+        if ids.shape != self.ids.shape or vals.shape != self.vals.shape:
+            raise ValueError(f"graph was captured for batch shape {tuple(self.ids.shape)}, got {tuple(ids.shape)}")
+        self.ids.copy_(ids)
+        self.vals.copy_(vals)
+        self.y.copy_(y)
+        self.graph.replay()
+        vals.copy_(self.vals)
+        return self.loss
+
+
 class _MLP(nn.Module):
     """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*).
 
@@ -396,11 +473,17 @@ class _MLP(nn.Module):
             mods = list(self.mlp)
             i = 0
             while i < len(mods):
-                if (i + 2 < len(mods) and isinstance(mods[i + 1], HipBatchNorm1d) and isinstance(mods[i + 2], nn.ReLU)):
-                    x = mods[i + 1](mods[i](x), relu=True)
+                m = mods[i]
+                if isinstance(m, nn.Linear) and m.bias is not None and x.dim() == 2 and x.shape[0] >= 2048:
+                    h = _LinearSplitKFn.apply(x.contiguous(), m.weight, m.bias)
+                else:
+                    h = m(x)
+                if (isinstance(m, nn.Linear) and i + 2 < len(mods) and isinstance(mods[i + 1], HipBatchNorm1d)
+                        and isinstance(mods[i + 2], nn.ReLU)):
+                    x = mods[i + 1](h, relu=True)
                     i += 3
                 else:
-                    x = mods[i](x)
+                    x = h
                     i += 1
             return x
         if self.training or torch.is_grad_enabled() or not x.is_cuda or not self.fold_eval:

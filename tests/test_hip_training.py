@@ -145,3 +145,47 @@ def test_hip_batchnorm_training_matches_float64_batchnorm(shape, relu):
         # ReLU: an element whose pre-activation is within rounding of 0 may flip; none of these seeds has one
         assert float((a.double() - b).abs().max()) / scale <= 2e-5, n
     assert got[6] == ref[6] == 1
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """GraphedTrainStep (one hipGraph per training step) against the same steps run eagerly: same batches, same
+    SGD with momentum (linear in the gradients: Adam's normalisation would amplify the float atomics' reordering
+    noise of near-zero gradients); parameters and BatchNorm buffers after 4 steps agree."""
+    from armnet_hip.modules import GraphedTrainStep
+    meta, sd, _, _, _ = load("h1_grad_1h_a1.7_train")
+    c = meta["ctor"]
+    g = torch.Generator().manual_seed(3)
+    B = 256
+    batches = [(torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g).to(DEV),
+                torch.rand(B, c["nfield"], generator=g).to(DEV),
+                (torch.rand(B, generator=g) > 0.5).float().to(DEV)) for _ in range(4)]
+    lossf = torch.nn.BCEWithLogitsLoss()
+    results = []
+    for graphed in (False, True):
+        m = build_model(meta, sd, DEV).train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+        losses = []
+        if graphed:
+            # the capture's warm-up steps must not move the weights: capture on a copy of the state, then restore
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            step = GraphedTrainStep(m, opt, lossf, *batches[0])
+            m.load_state_dict(state)
+            for st in opt.state.values():
+                st["momentum_buffer"].zero_()          # momentum starts from zero like the eager run's first step
+            for ids, vals, y in batches:
+                losses.append(float(step(ids, vals.clone(), y)))
+        else:
+            for ids, vals, y in batches:
+                opt.zero_grad(set_to_none=True)
+                loss = lossf(m({"id": ids, "value": vals.clone()}), y)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            continue
+        a, b = s0[k].float(), s1[k].float()
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3), k

@@ -35,5 +35,14 @@ def main():
     for _ in range(n): fb()
     torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / n
     print(f"B={B} alpha={alpha}: train step {dt*1e3:.2f} ms ({B/dt/1e3:.0f} k samples/s); fwd+bwd only {dt2*1e3:.2f} ms")
+    # the same step replayed as one hipGraph
+    from armnet_hip.modules import GraphedTrainStep
+    opt2 = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    gstep = GraphedTrainStep(m, opt2, lossf, ids, vals, y)
+    for _ in range(3): gstep(ids, vals, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): gstep(ids, vals, y)
+    torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / n
+    print(f"B={B} alpha={alpha}: graphed train step {dt3*1e3:.2f} ms ({B/dt3/1e3:.0f} k samples/s)")
 
 main()
