@@ -18,10 +18,11 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
     const bool c16 = (a.E % 4 == 0);
     if (((uintptr_t)a.table % (c16 ? 16 : 8))) return ARMNET_ERR_UNSUPPORTED;
     if (a.E % 16 == 0 && (((uintptr_t)a.z % 16) || ((uintptr_t)a.dz % 16))) return ARMNET_ERR_UNSUPPORTED;
-    // slices of kBwdSlice neurons: each re-stages the rows and adds its part of dx to the table gradient
-    for (int o0 = 0; o0 < a.O; o0 += kBwdSlice) {
+    // slices of 32 (nemb = 64: 16) neurons: each re-stages the rows and adds its part of dx to the table gradient
+    const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64);
+    for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
-        s.O = a.O - o0 < kBwdSlice ? a.O - o0 : kBwdSlice;
+        s.O = a.O - o0 < slice ? a.O - o0 : slice;
         s.O_all = a.O_all ? a.O_all : a.O;
         s.q_fold = a.q_fold + (size_t)o0 * a.E;
         s.values = a.values + (size_t)o0 * a.F;

@@ -29,6 +29,8 @@ constexpr int kBwdSlice = 32;     // neurons per launch = 2 passes: the d_values
                                   // stay in registers over all samples of a wave (LDS float atomics from 4 waves on
                                   // the same addresses cost more than the rest of the kernel: measured 888 -> 368 us)
 constexpr int kBwdNT = kBwdSlice / 16;
+// nemb = 64: one pass per launch (the per-wave accumulators of two passes do not fit beside the dx tiles)
+constexpr int bwd_passes(int E) { return E >= 64 ? 1 : kBwdNT; }
 
 template <int E, int NQ, int MODE, int SRC, int CB>
 __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
@@ -110,10 +112,14 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         zoff[m] = (q < 4 * NTILE) ? ((q >> 2) * 16 + 4 * gg + (q & 3)) * ES + 4 * cc : -1;
     }
     const bool full_rows = (Er == E);
-    // ablation switches for profiling (tools/bwd_bench.py --flags); never set by the product path
+    // ablation switches for profiling (tools/bwd_bench.py --flags against a `make EXTRA=-DARMNET_DEV_FLAGS` build)
+#ifdef ARMNET_DEV_FLAGS
     const bool dbg_no_scatter = (a.flags & 0x400u) != 0;   // skip the d_table atomics
     const bool dbg_one_pass = (a.flags & 0x2000u) != 0;    // only the first 16-neuron pass
     const bool dbg_hot_rows = (a.flags & 0x200u) != 0;     // fold ids into 1024 rows
+#else
+    constexpr bool dbg_no_scatter = false, dbg_one_pass = false, dbg_hot_rows = false;
+#endif
 
     // ---- block prologue: parameters of this neuron slice, zeroed accumulators -------------------------
     for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
@@ -154,10 +160,11 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const float two_m_alpha = 2.0f - a.alpha;
 
     // per-wave accumulators over all its samples: d_values in the C layout, d_qfold^T as MFMA #4's accumulator
-    float dvacc[kBwdNT][NQ];
-    f32x4 dqacc[kBwdNT][EB];
+    constexpr int NTS = bwd_passes(E);
+    float dvacc[NTS][NQ];
+    f32x4 dqacc[NTS][EB];
 #pragma unroll
-    for (int n = 0; n < kBwdNT; ++n) {
+    for (int n = 0; n < NTS; ++n) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) dvacc[n][j] = 0.f;
 #pragma unroll
@@ -277,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             for (int eb = 0; eb < EB; ++eb) cdx[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-        for (int nt = 0; nt < kBwdNT; ++nt) {
+        for (int nt = 0; nt < NTS; ++nt) {
             if (nt >= npass) break;                                      // wave-uniform
             // ---- ds = dz * z of this lane's neuron: the B operand of MFMA #3 (fetched one pass ahead) ----------
             f32x4 ds4[EB];
@@ -315,6 +322,10 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                             c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
+            // inline-asm readers of the accumulators follow (see fused_mfma_kernel.h): XDL write -> VALU read hazard
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15");
+            __builtin_amdgcn_sched_barrier(0);
 #define XG(j) c1[(j) >> 2][(j) & 3]
 #define XP_GET(jp) (f32x2{XG(2 * (jp)), XG(2 * (jp) + 1)})
 #define XP_SET(jp, v)            \
@@ -560,7 +571,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     }
     // ---- wave accumulators -> block accumulators (LDS atomics, once per wave) -> global ------------------------
 #pragma unroll
-    for (int nt = 0; nt < kBwdNT; ++nt) {
+    for (int nt = 0; nt < NTS; ++nt) {
         if (nt >= NT) break;
         float* dv_row = acc_dv + (16 * nt + c) * FP + g;
 #pragma unroll

@@ -159,11 +159,17 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const bool two_pad = F <= 4 * (NQ - 1);              // the even rounding of NQ added a whole pad quarter-step
     const bool write_vals = (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) != 0;
     const bool check_ids = a.id_status != nullptr;
-    // ablation switches for profiling (tools/kbench.py); never set by the product path
+    // ablation switches for profiling (tools/kbench.py against a `make EXTRA=-DARMNET_DEV_FLAGS` build)
+#ifdef ARMNET_DEV_FLAGS
     const bool dbg_no_solve = (a.flags & 0x100u) != 0;   // skip the Newton iterations
     const bool dbg_hot_rows = (a.flags & 0x200u) != 0;   // fold ids into 1024 rows (cache-resident gather)
     const bool dbg_no_store = (a.flags & 0x400u) != 0;   // skip the output stores
     const bool dbg_no_mfma = (a.flags & 0x800u) != 0;    // replace the MFMAs by register copies
+#else
+    // product build: the switches are compile-time false (a runtime test in front of every MFMA of the unrolled
+    // second contraction splits it into 20 basic blocks)
+    constexpr bool dbg_no_solve = false, dbg_hot_rows = false, dbg_no_store = false, dbg_no_mfma = false;
+#endif
     const uint32_t id_mask = dbg_hot_rows ? 1023u : 0xffffffffu;
     const uint32_t id_max = (uint32_t)a.nfeat - 1u;
     // lanes whose chunk lies in the zero padding of a row (nemb < E) read zeros: lane-constant base and stride
@@ -362,6 +368,12 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                             c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
+            // The sparse map below reads the accumulators through inline asm (v_max3_f32, v_pk_add_f32 ... clamp), which
+            // the compiler's hazard recognizer does not look into: an XDL write must be 11+ wait states old before a
+            // VALU read.  Pin the MFMAs above this point and wait once (16 states against ~3000 cycles per pass).
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15");
+            __builtin_amdgcn_sched_barrier(0);
             PHASE(1);
             // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
 #define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]

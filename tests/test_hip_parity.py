@@ -367,3 +367,32 @@ def test_device_resident_loader_feeds_the_model():
     torch.testing.assert_close(torch.cat(outs), want, rtol=1e-5, atol=1e-6)
     shuffled = [b["y"].numel() for b in DeviceLoader(ds, batch_size=48, shuffle=True, device=DEV, drop_last=True)]
     assert shuffled == [48, 48]
+
+
+@pytest.mark.parametrize("E", [2, 10, 16, 20, 32, 64])
+def test_matrix_core_kernel_agrees_with_generic_kernel_for_every_nfield(E):
+    """every nfield 1..48 x neuron counts x alpha for one nemb family, matrix-core kernel vs the shape-agnostic one
+    (itself pinned by the golden vectors) on random stressed inputs.  This scan is what caught an XDL-write ->
+    inline-asm-read hazard that only some (nemb, nfield) instantiations scheduled badly."""
+    from armnet_hip import native
+    B, nfeat = 37, 53
+    worst, n = 0.0, 0
+    for F in range(1, 49):
+        for O in (7, 24, 40):
+            for alpha in (1.0, 1.5, 2.0):
+                if native.fused_kernel_kind(F, E, O, alpha) != 1:
+                    continue
+                g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
+                table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
+                qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+                values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+                ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+                vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+                sc, sh = (torch.rand(O, generator=g) + 0.5).to(DEV), torch.randn(O, generator=g).to(DEV)
+                z, zg = torch.empty(B, O, E, device=DEV), torch.empty(B, O, E, device=DEV)
+                native.fused_fwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, sc, sh, z)
+                native.fused_fwd(B, F, E, O, alpha, 50, native.F_FORCE_GENERIC, ids, vals, table, qf, values, sc, sh, zg)
+                err = float((z - zg).abs().max()) / max(1.0, float(zg.abs().max()))
+                assert err <= TOL, f"nfield={F} nemb={E} neurons={O} alpha={alpha}: {err}"
+                worst, n = max(worst, err), n + 1
+    assert n == 48 * 9
