@@ -322,10 +322,6 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                             c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
-            // inline-asm readers of the accumulators follow (see fused_mfma_kernel.h): XDL write -> VALU read hazard
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15");
-            __builtin_amdgcn_sched_barrier(0);
 #define XG(j) c1[(j) >> 2][(j) & 3]
 #define XP_GET(jp) (f32x2{XG(2 * (jp)), XG(2 * (jp) + 1)})
 #define XP_SET(jp, v)            \
@@ -353,9 +349,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                 }
                 XG(NQ - 1) += padneg_a;
                 if (two_pad) XG(NQ - 2) += padneg_b;
-                float mx = XG(0);
+                float mx = cmax2(XG(0), XG(1));             // compiler-visible first readers of the accumulators
 #pragma unroll
-                for (int j = 1; j < NQ; ++j) mx = vmax2(mx, XG(j));
+                for (int j = 2; j + 1 < NQ; j += 2) mx = cmax3(mx, XG(j), XG(j + 1));
                 red_write(red, 0, lane, mx, sm2[0] + sm2[1]);
                 wave_lds_fence();
                 const Red2 r = red_read(red, 0, c);

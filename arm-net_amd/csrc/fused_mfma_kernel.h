@@ -94,6 +94,13 @@ __device__ __forceinline__ float vmax2(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The asm forms above must NOT read MFMA accumulators: the compiler's hazard recognizer does not look into inline
+// asm and an XDL write has to be >= 12 wait states old before a VALU read (seen as NaNs / wrong thresholds in the
+// instantiations that happened to schedule a v_max3 right behind the last MFMA).  The first readers of the gate
+// accumulators are therefore these compiler-visible maxima (MFMA results count as canonical: no extra v_max x,x);
+// everything in asm that touches the gates afterwards depends on their result.
+__device__ __forceinline__ float cmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 
 
 // E = nemb padded to 16/32/64; NQ = quarter-steps per sample (even); SPW samples per wave-group;
@@ -368,12 +375,6 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                             c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
                     }
             }
-            // The sparse map below reads the accumulators through inline asm (v_max3_f32, v_pk_add_f32 ... clamp), which
-            // the compiler's hazard recognizer does not look into: an XDL write must be 11+ wait states old before a
-            // VALU read.  Pin the MFMAs above this point and wait once (16 states against ~3000 cycles per pass).
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15");
-            __builtin_amdgcn_sched_barrier(0);
             PHASE(1);
             // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
 #define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]
@@ -407,13 +408,13 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 XG(s, NQ - 1) += padneg_a;                  // pad fields -> -inf (never in the support)
                 if (two_pad) XG(s, NQ - 2) += padneg_b;     // wave-uniform
                 float mx;
-                if constexpr (NQ == 2) {
-                    mx = vmax2(XG(s, 0), XG(s, 1));
+                if constexpr (NQ == 2) {                    // compiler-visible: first readers of the accumulators
+                    mx = cmax2(XG(s, 0), XG(s, 1));
                 } else {
-                    mx = vmax3(XG(s, 0), XG(s, 1), XG(s, 2));
+                    mx = cmax3(XG(s, 0), XG(s, 1), XG(s, 2));
 #pragma unroll
-                    for (int j = 3; j + 1 < NQ; j += 2) mx = vmax3(mx, XG(s, j), XG(s, j + 1));
-                    mx = vmax2(mx, XG(s, NQ - 1));
+                    for (int j = 3; j + 1 < NQ; j += 2) mx = cmax3(mx, XG(s, j), XG(s, j + 1));
+                    mx = cmax2(mx, XG(s, NQ - 1));
                 }
                 red_write(red, s & 1, lane, mx, sm2[0] + sm2[1]);
             }
