@@ -162,6 +162,11 @@ def pmc_traffic(a):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when the first communicator
+    # is created, so everything else written to fd 1 by any library goes to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.shard is None:
         a.shard = "both" if world > 1 else "replicate"
@@ -198,23 +203,41 @@ def main():
     wall_ms, ev_ms = timed(step_block, a.steps, sync_all)
     full_wall_ms, _ = timed(step_full, a.steps, sync_all)
 
-    sharded_ms, sharded_err = float("nan"), None
-    if a.shard == "both":
-        # same model, same batch, but the table row-sharded over the ranks and fetched by all-to-all.
-        # A deterministic failure here (every rank raises the same way) must not cost the main line.
-        try:
-            model.shard_embedding()
-            for _ in range(a.warmup):
-                step_block()
-            sharded_ms, _ = timed(step_block, a.steps, sync_all)
-        except Exception as e:  # noqa: BLE001
-            sharded_err = f"{type(e).__name__}: {e}"
-        model._shard = None
-
-    t = torch.tensor([wall_ms, ev_ms, full_wall_ms, sharded_ms], device=dev, dtype=torch.float64)
+    t = torch.tensor([wall_ms, ev_ms, full_wall_ms], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_ms, ev_ms, full_wall_ms, sharded_ms = t.tolist()
+    wall_ms, ev_ms, full_wall_ms = t.tolist()
+
+    # Row-sharded variant: same model, same batch, the table row-sharded over the ranks and fetched by all-to-all.
+    # It runs AFTER the headline numbers are final and under a watchdog: whatever happens in there (an exception on
+    # one rank, a collective that never completes) must not cost the main line.
+    sharded = {"ms": float("nan"), "err": None, "done": False}
+    if a.shard == "both":
+        import threading
+
+        def run_sharded():
+            try:
+                torch.cuda.set_device(local)
+                model.shard_embedding()
+                for _ in range(a.warmup):
+                    step_block()
+                ms, _ = timed(step_block, a.steps, sync_all)
+                ts = torch.tensor([ms], device=dev, dtype=torch.float64)
+                if use_dist:
+                    dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                sharded["ms"] = float(ts.item())
+            except Exception as e:  # noqa: BLE001
+                sharded["err"] = f"{type(e).__name__}: {e}"
+            sharded["done"] = True
+
+        th = threading.Thread(target=run_sharded, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "180")))
+        if not sharded["done"]:
+            sharded["err"] = "timeout: the row-sharded measurement did not complete (collective hang?)"
+    sharded_ms, sharded_err = sharded["ms"], sharded["err"]
+    if sharded_err is None and a.shard == "both":
+        model._shard = None
 
     if rank == 0:
         ms_per_step = wall_ms / a.steps
@@ -258,7 +281,9 @@ def main():
                         f"across xGMI), fused kernel over (rows, perm)"}
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             line["cpu_baseline"] = cpu_baseline(a, model, ids_cpu, vals_cpu)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if a.shard == "both" and not sharded["done"]:
+        os._exit(0)                 # a stuck collective: leave without tearing the process group down
     if use_dist:
         dist.destroy_process_group()
 
