@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Large-batch scan (developer tool, GPU box): persistent-loop / pipeline paths of the matrix-core kernels (several
+groups per wave, short last group, int32 ids, pre-gathered rows, value write-back) against the shape-agnostic kernels."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "arm-net_amd")):
+    sys.path.insert(0, p)
+import torch
+from armnet_hip import native
+
+DEV = "cuda:0"
+nfeat = 5003
+bad = n = 0
+for B in (20011, 65537):
+    for F in (1, 3, 7, 10, 13, 16, 22, 24, 31, 39, 43, 48):
+        for E in (2, 10, 16, 20, 32, 64):
+            for O, alpha in ((7, 2.0), (32, 1.5), (40, 1.0), (24, 1.7)):
+                if native.fused_kernel_kind(F, E, O, alpha) != 1:
+                    continue
+                g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
+                table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
+                qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+                values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+                ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+                vals0 = (torch.rand(B, F, generator=g) * 1.2 - 0.1).to(DEV)          # some outside [1e-3, 1]
+                sc, sh = (torch.rand(O, generator=g) + 0.5).to(DEV), torch.randn(O, generator=g).to(DEV)
+                outs = {}
+                for name, flags, idt in (("gen", native.F_FORCE_GENERIC | native.F_WRITE_CLAMPED_VALS, ids),
+                                         ("mfma", native.F_WRITE_CLAMPED_VALS, ids),
+                                         ("mfma32", native.F_WRITE_CLAMPED_VALS, ids.to(torch.int32))):
+                    v = vals0.clone()
+                    z = torch.empty(B, O, E, device=DEV)
+                    native.fused_fwd(B, F, E, O, alpha, 50, flags, idt, v, table, qf, values, sc, sh, z)
+                    outs[name] = (z, v)
+                rows = table[ids].contiguous()
+                v = vals0.clone(); z = torch.empty(B, O, E, device=DEV)
+                native.fused_fwd_from_rows(B, F, E, O, alpha, 50, native.F_WRITE_CLAMPED_VALS, rows, v, qf, values, sc, sh, z)
+                outs["rows"] = (z, v)
+                zg, vg = outs["gen"]
+                n += 1
+                for k in ("mfma", "mfma32", "rows"):
+                    z, v = outs[k]
+                    err = float((z - zg).abs().max()) / max(1.0, float(zg.abs().max()))
+                    if not (err <= 1e-5) or not torch.equal(v, vg):
+                        bad += 1
+                        print(f"{k} mismatch B={B} F={F} E={E} O={O} alpha={alpha}: {err} vals_equal={torch.equal(v, vg)}")
+print(f"{n} cases, {bad} disagreements")
