@@ -6,9 +6,10 @@
 // and two HBM-bound elementwise passes per layer and step.  All four are one pass over x viewed as
 // [N, C, L] (L = 1 for 2-D input) with the same skeleton:
 //
-//   a thread owns inner positions i = c * L + l (coalesced across the wave), so its channel parameters are
-//   loaded once per position; a block owns a contiguous range of the N rows; reductions go thread -> LDS
-//   (one atomic per thread and position) -> one global atomic per channel and block.
+//   a thread owns ONE inner position i = c * L + l (coalesced across the wave), so its channel parameters are
+//   loaded once; a block owns 256 positions and a contiguous range of the N rows, two batches of 8 rows in flight
+//   per thread (the passes are latency-bound otherwise); reductions go thread -> LDS (one atomic per thread) ->
+//   one global atomic per channel and block.
 //
 // Variance uses sums shifted by k[c] = x[0, c, 0] (the exponential neurons have |mean| >> std: the plain
 // E[x^2] - E[x]^2 would cancel).  Optional fused ReLU (the MLP's BatchNorm1d -> ReLU, layers.py:77-78):
@@ -43,14 +44,18 @@ __global__ void __launch_bounds__(BN_TPB) bn_pass_kernel(BnArgs a) {
     extern __shared__ float acc[];                       // [2C] for the reducing ops
     const int CL = a.C * a.L;
     constexpr bool REDUCE = (OP == BN_STATS || OP == BN_BWD_REDUCE);
+    constexpr bool HAS_DY = (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY);
+    constexpr bool WRITES = (OP == BN_APPLY || OP == BN_BWD_APPLY);
     if constexpr (REDUCE) {
         for (int i = threadIdx.x; i < 2 * a.C; i += BN_TPB) acc[i] = 0.f;
         __syncthreads();
     }
+    // blockIdx.y: which 256 inner positions (a thread owns ONE position i = c * L + l); blockIdx.x: which rows
+    const int i = blockIdx.y * BN_TPB + threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_block;
     int64_t n1 = n0 + a.rows_per_block;
     if (n1 > a.N) n1 = a.N;
-    for (int i = threadIdx.x; i < CL; i += BN_TPB) {
+    if (i < CL) {
         const int c = i / a.L;
         float q0 = 0.f, q1 = 0.f, q2 = 0.f, r0 = 0.f, r1 = 0.f;
         bool mask = false;
@@ -58,71 +63,62 @@ __global__ void __launch_bounds__(BN_TPB) bn_pass_kernel(BnArgs a) {
         if constexpr (OP == BN_APPLY) { q0 = a.p0[c]; q1 = a.p1[c]; }
         if constexpr (OP == BN_BWD_REDUCE) { q0 = a.p0[c]; q1 = a.p1[c]; }
         if constexpr (OP == BN_BWD_APPLY) { q0 = a.p0[c]; q1 = a.p1[c]; q2 = a.p2[c]; }
-        if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) {
+        if constexpr (HAS_DY) {
             mask = a.rs != nullptr;
             if (mask) { r0 = a.rs[c]; r1 = a.rt[c]; }
         }
         float s1 = 0.f, s2 = 0.f;
         const float* xp = a.x + (size_t)n0 * CL + i;
-        const float* gp = (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) ? a.dy + (size_t)n0 * CL + i : nullptr;
-        float* op = (OP == BN_APPLY || OP == BN_BWD_APPLY) ? a.out + (size_t)n0 * CL + i : nullptr;
-        int64_t n = n0;
-        for (; n + BN_UNROLL <= n1; n += BN_UNROLL) {
-            float xv[BN_UNROLL], gv[BN_UNROLL];
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) {
-                xv[u] = xp[(size_t)u * CL];
-                if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gv[u] = gp[(size_t)u * CL];
-            }
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) {
-                if constexpr (OP == BN_STATS) {
-                    const float d = xv[u] - q0;
-                    s1 += d;
-                    s2 = fmaf(d, d, s2);
-                } else if constexpr (OP == BN_APPLY) {
-                    float y = fmaf(xv[u], q0, q1);
-                    if (a.relu) y = y > 0.f ? y : (y != y ? y : 0.f);               // NaN stays NaN like torch.relu
-                    op[(size_t)u * CL] = y;
-                } else {
-                    float g = gv[u];
-                    if (mask) g = fmaf(xv[u], r0, r1) > 0.f ? g : 0.f;
-                    if constexpr (OP == BN_BWD_REDUCE) {
-                        s1 += g;
-                        s2 = fmaf(g, (xv[u] - q0) * q1, s2);        // dy * xhat
-                    } else {
-                        op[(size_t)u * CL] = fmaf(q0, g, fmaf(q2, xv[u], q1));
-                    }
-                }
-            }
-            xp += (size_t)BN_UNROLL * CL;
-            if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gp += (size_t)BN_UNROLL * CL;
-            if constexpr (OP == BN_APPLY || OP == BN_BWD_APPLY) op += (size_t)BN_UNROLL * CL;
-        }
-        for (; n < n1; ++n) {
-            const float xv = *xp;
+        const float* gp = HAS_DY ? a.dy + (size_t)n0 * CL + i : nullptr;
+        float* op = WRITES ? a.out + (size_t)n0 * CL + i : nullptr;
+        const bool relu = a.relu != 0;
+
+        auto one = [&](float xv, float gv, float* dst) {
             if constexpr (OP == BN_STATS) {
                 const float d = xv - q0;
                 s1 += d;
                 s2 = fmaf(d, d, s2);
             } else if constexpr (OP == BN_APPLY) {
                 float y = fmaf(xv, q0, q1);
-                if (a.relu) y = y > 0.f ? y : (y != y ? y : 0.f);
-                *op = y;
+                if (relu) y = y > 0.f ? y : (y != y ? y : 0.f);                     // NaN stays NaN like torch.relu
+                *dst = y;
             } else {
-                float g = *gp;
+                float g = gv;
                 if (mask) g = fmaf(xv, r0, r1) > 0.f ? g : 0.f;
                 if constexpr (OP == BN_BWD_REDUCE) {
                     s1 += g;
-                    s2 = fmaf(g, (xv - q0) * q1, s2);
+                    s2 = fmaf(g, (xv - q0) * q1, s2);                               // dy * xhat
                 } else {
-                    *op = fmaf(q0, g, fmaf(q2, xv, q1));
+                    *dst = fmaf(q0, g, fmaf(q2, xv, q1));
                 }
             }
-            xp += CL;
-            if constexpr (OP == BN_BWD_REDUCE || OP == BN_BWD_APPLY) gp += CL;
-            if constexpr (OP == BN_APPLY || OP == BN_BWD_APPLY) op += CL;
+        };
+        auto load = [&](float (&xv)[BN_UNROLL], float (&gv)[BN_UNROLL], int64_t row) {
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                xv[u] = xp[(size_t)(row + u) * CL];
+                if constexpr (HAS_DY) gv[u] = gp[(size_t)(row + u) * CL];
+            }
+        };
+        auto consume = [&](const float (&xv)[BN_UNROLL], const float (&gv)[BN_UNROLL], int64_t row) {
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) one(xv[u], HAS_DY ? gv[u] : 0.f, WRITES ? op + (size_t)(row + u) * CL : nullptr);
+        };
+        // two batches of BN_UNROLL rows in flight (ping-pong registers): the pass is latency-bound otherwise
+        const int64_t rows = n1 - n0;
+        const int64_t nb = rows / BN_UNROLL;
+        float xa[BN_UNROLL], ga[BN_UNROLL], xb[BN_UNROLL], gb[BN_UNROLL];
+        if (nb > 0) load(xa, ga, 0);
+        int64_t b = 0;
+        for (; b + 2 <= nb; b += 2) {
+            load(xb, gb, (b + 1) * BN_UNROLL);
+            consume(xa, ga, b * BN_UNROLL);
+            if (b + 2 < nb) load(xa, ga, (b + 2) * BN_UNROLL);
+            consume(xb, gb, (b + 1) * BN_UNROLL);
         }
+        if (b < nb) consume(xa, ga, b * BN_UNROLL);
+        for (int64_t r = nb * BN_UNROLL; r < rows; ++r)
+            one(xp[(size_t)r * CL], HAS_DY ? gp[(size_t)r * CL] : 0.f, WRITES ? op + (size_t)r * CL : nullptr);
         if constexpr (REDUCE) {
             atomicAdd(&acc[c], s1);
             atomicAdd(&acc[a.C + c], s2);
@@ -130,21 +126,33 @@ __global__ void __launch_bounds__(BN_TPB) bn_pass_kernel(BnArgs a) {
     }
     if constexpr (REDUCE) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * a.C; i += BN_TPB) unsafeAtomicAdd(a.sums + i, acc[i]);
+        // this block saw only the channels of its 256 positions
+        const int c_lo = (blockIdx.y * BN_TPB) / a.L;
+        int c_hi = (blockIdx.y * BN_TPB + BN_TPB - 1) / a.L;
+        if (c_hi >= a.C) c_hi = a.C - 1;
+        for (int c = c_lo + threadIdx.x; c <= c_hi; c += BN_TPB) {
+            unsafeAtomicAdd(a.sums + c, acc[c]);
+            unsafeAtomicAdd(a.sums + a.C + c, acc[a.C + c]);
+        }
     }
 }
 
 template <int OP>
 static int launch_bn_pass(BnArgs a, hipStream_t st) {
     if (a.N == 0) return ARMNET_OK;
-    // ~8 blocks per CU; at least BN_UNROLL rows per block so the unrolled loop is the common path
-    int64_t rpb = (a.N + 2047) / 2048;
-    if (rpb < BN_UNROLL) rpb = BN_UNROLL;
+    const int64_t CL = (int64_t)a.C * a.L;
+    const int ny = (int)((CL + BN_TPB - 1) / BN_TPB);
+    if (ny > 65535) return ARMNET_ERR_UNSUPPORTED;
+    // ~8 blocks per CU in total; at least 2 * BN_UNROLL rows per block so the pipelined loop is the common path
+    int64_t nx = 2048 / ny;
+    if (nx < 1) nx = 1;
+    int64_t rpb = (a.N + nx - 1) / nx;
+    if (rpb < 2 * BN_UNROLL) rpb = 2 * BN_UNROLL;
     a.rows_per_block = (int)rpb;
-    const int64_t grid = (a.N + rpb - 1) / rpb;
+    nx = (a.N + rpb - 1) / rpb;
     const size_t lds = (OP == BN_STATS || OP == BN_BWD_REDUCE) ? (size_t)2 * a.C * sizeof(float) : 0;
     if (lds > 64 * 1024) return ARMNET_ERR_UNSUPPORTED;
-    bn_pass_kernel<OP><<<(int)grid, BN_TPB, lds, st>>>(a);
+    bn_pass_kernel<OP><<<dim3((unsigned)nx, (unsigned)ny), BN_TPB, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
