@@ -45,3 +45,32 @@ for B in (20011, 65537):
                         bad += 1
                         print(f"{k} mismatch B={B} F={F} E={E} O={O} alpha={alpha}: {err} vals_equal={torch.equal(v, vg)}")
 print(f"{n} cases, {bad} disagreements")
+
+# backward, large batch: pipelined loads past the end, several samples per wave, BatchNorm coefficients folded in
+bad = n = 0
+for B in (20011,):
+    for F, E, O, alpha in ((39, 16, 32, 2.0), (39, 10, 128, 1.5), (22, 32, 40, 2.0), (43, 64, 24, 1.7), (10, 10, 70, 1.0),
+                           (3, 2, 7, 2.0), (48, 20, 33, 2.0), (13, 48, 16, 1.5)):
+        g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
+        table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
+        qf = (torch.randn(O, E, generator=g) * 0.5).to(DEV)
+        values = (torch.randn(O, F, generator=g) * 0.3).to(DEV)
+        ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+        vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+        one, zero = torch.ones(O, device=DEV), torch.zeros(O, device=DEV)
+        z = torch.empty(B, O, E, device=DEV)
+        native.fused_fwd(B, F, E, O, alpha, 50, native.F_FORCE_GENERIC, ids, vals, table, qf, values, one, zero, z)
+        dy = torch.randn(B, O, E, generator=g).to(DEV)
+        cA, cB, cC = (torch.rand(O, generator=g) + 0.5).to(DEV), (torch.randn(O, generator=g) * 0.1).to(DEV), (torch.randn(O, generator=g) * 0.1).to(DEV)
+        outs = []
+        for flags in (native.F_FORCE_GENERIC, 0):
+            dt, dv, dq = torch.zeros_like(table), torch.zeros_like(values), torch.zeros_like(qf)
+            native.fused_bwd_bn(B, F, E, O, alpha, 50, flags, ids, vals, table, qf, values, z, dy, cA, cB, cC, dt, dv, dq)
+            outs.append((dt, dv, dq))
+        n += 1
+        for nm, a, b in zip(("d_table", "d_values", "d_qfold"), outs[1], outs[0]):
+            e2 = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+            if not (e2 <= 1e-4):
+                bad += 1
+                print(f"BWD mismatch B={B} F={F} E={E} O={O} alpha={alpha} {nm}: {e2}")
+print(f"backward: {n} cases, {bad} disagreements")
