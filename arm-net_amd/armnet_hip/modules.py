@@ -26,7 +26,7 @@ class _GatherScaleFn(torch.autograd.Function):
         ids, vals = ctx.saved_tensors
         E = g.shape[-1]
         d_table = torch.zeros(ctx.nfeat, E, device=g.device, dtype=g.dtype)
-        d_table.index_add_(0, ids.reshape(-1), (g * vals.unsqueeze(-1)).reshape(-1, E))
+        native.scatter_add(ids.contiguous(), vals.contiguous(), g.contiguous(), d_table)
         return d_table, None, None, None
 
 
@@ -335,7 +335,11 @@ class ArmNetBase(nn.Module):
             self.deep_embedding.check_ids = False                # ids were validated by the fused call
             x_deep = self.deep_embedding({"id": ids, "value": v})  # sees the clamped values (armnet.py:94)
             y_deep = self.deep_mlp(x_deep.view(x_deep.shape[0], -1))
-            y = self.ensemble_layer(torch.cat([y, y_deep], dim=1))
+            yy = torch.cat([y, y_deep], dim=1)
+            if self.training and yy.shape[0] >= 2048:           # tiny-N, huge-K weight gradient: split-K
+                y = _LinearSplitKFn.apply(yy, self.ensemble_layer.weight, self.ensemble_layer.bias)
+            else:
+                y = self.ensemble_layer(yy)
         return y.squeeze()
 
 

@@ -28,6 +28,7 @@ EXPORTS = (
     "armnet_fused_bwd_f32", "armnet_shard_route_unique_ws_bytes", "armnet_shard_route_unique_ids",
     "armnet_fused_kernel_kind", "armnet_fused_bwd_bn_f32", "armnet_bn_stats_f32", "armnet_bn_finalize_f32",
     "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
+    "armnet_scatter_add_f32",
 )
 
 _lib = None
@@ -194,6 +195,18 @@ def fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values
                                       ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
                                       ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
                                       _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+
+
+def scatter_add(ids, vals, grad, d_table):
+    """d_table[ids[r], :] += grad[r, :] * vals[r] (backward of gather_scale with respect to the table)"""
+    if not (ids.is_cuda and ids.is_contiguous()):
+        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    _dev_f32(grad, "grad"); _dev_f32(d_table, "d_table")
+    if vals is not None:
+        _dev_f32(vals, "vals")
+    n, E = ids.numel(), d_table.shape[1]
+    check(load().armnet_scatter_add_f32(ctypes.c_int64(n), E, _ptr(ids), _id_type(ids), _ptr(vals), _ptr(grad),
+                                        ctypes.c_int64(d_table.shape[0]), _ptr(d_table), _stream()))
 
 
 def fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, z, dy, coefA, coefB, coefC,

@@ -106,6 +106,14 @@ int armnet_gather_scale_f32(int64_t n_rows, int E, const void* ids, int id_type,
                                (hipStream_t)stream);
 }
 
+int armnet_scatter_add_f32(int64_t n_rows, int E, const void* ids, int id_type, const float* vals, const float* grad,
+                           int64_t nfeat, float* d_table, void* stream) {
+    if (n_rows < 0 || E <= 0 || !ids || !grad || !d_table || nfeat <= 0) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    return launch_scatter_add(n_rows, E, ids, id_type, vals, grad, nfeat, d_table, (hipStream_t)stream);
+}
+
 int armnet_clamp_vals_f32(float* vals, int64_t n, void* stream) {
     if (n < 0 || (!vals && n > 0)) return ARMNET_ERR_BAD_ARG;
     return launch_clamp_vals(vals, n, (hipStream_t)stream);

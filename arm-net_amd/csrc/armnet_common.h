@@ -260,6 +260,8 @@ struct BwdArgs {
     uint32_t flags;
 };
 
+int launch_scatter_add(int64_t n_rows, int E, const void* ids, int id_type, const float* vals, const float* g,
+                       int64_t nfeat, float* d_table, hipStream_t s);
 int launch_fused_generic(const FusedArgs& a, hipStream_t s);
 // returns ARMNET_ERR_UNSUPPORTED when the shape has no MFMA specialisation
 int launch_fused_mfma(const FusedArgs& a, hipStream_t s);

@@ -96,6 +96,36 @@ int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, con
     return ARMNET_OK;
 }
 
+// Backward of the lookup alone (layers.py:20-21): d_table[ids[r], :] += g[r, :] * vals[r], float atomics, one lane per
+// element (adjacent lanes share a row: 4E-byte runs).
+template <typename IdT>
+__global__ void scatter_add_kernel(int64_t n_rows, int E, const IdT* __restrict__ ids, const float* __restrict__ vals,
+                                   const float* __restrict__ g, int64_t nfeat, float* __restrict__ d_table) {
+    const int64_t total = n_rows * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / E;
+        const int e = (int)(i - r * E);
+        bool bad;
+        const uint32_t id = load_id_checked(ids + r, nfeat, bad);
+        if (bad) continue;                               // the forward already raised on it
+        const float v = vals ? vals[r] : 1.0f;
+        unsafeAtomicAdd(d_table + (size_t)id * E + e, g[i] * v);
+    }
+}
+
+int launch_scatter_add(int64_t n_rows, int E, const void* ids, int id_type, const float* vals, const float* g,
+                       int64_t nfeat, float* d_table, hipStream_t s) {
+    if (n_rows == 0) return ARMNET_OK;
+    int64_t grid = (n_rows * E + 255) / 256;
+    if (grid > 256 * 32) grid = 256 * 32;
+    if (id_type == ARMNET_ID_I64)
+        scatter_add_kernel<int64_t><<<(int)grid, 256, 0, s>>>(n_rows, E, (const int64_t*)ids, vals, g, nfeat, d_table);
+    else
+        scatter_add_kernel<int32_t><<<(int)grid, 256, 0, s>>>(n_rows, E, (const int32_t*)ids, vals, g, nfeat, d_table);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
 __global__ void clamp_vals_kernel(float* vals, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         vals[i] = clamp_val(vals[i]);

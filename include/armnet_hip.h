@@ -124,6 +124,14 @@ int armnet_gather_scale_f32(int64_t n_rows, int E, const void* ids, int id_type,
                             const float* table, int64_t nfeat, float* out, int32_t* id_status,
                             void* stream);
 
+/*
+ * Backward of armnet_gather_scale_f32 with respect to the table (what autograd derives for nn.Embedding followed by
+ * the multiply, layers.py:20-21): d_table[ids[r], :] += grad[r, :] * vals[r]  (float atomics; vals may be NULL).
+ * Used by the ensemble branch's second table in training.
+ */
+int armnet_scatter_add_f32(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
+                           const float* grad, int64_t nfeat, float* d_table, void* stream);
+
 /* armnet_1h.py:81 alone: vals <- clamp(vals, 1e-3, 1) in place. */
 int armnet_clamp_vals_f32(float* vals, int64_t n, void* stream);
 
