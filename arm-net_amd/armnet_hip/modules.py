@@ -37,13 +37,7 @@ class _ArmBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, bilinear_w, query, values, ids, vals, cfg):
         variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
-        dev = query.device
-        O = K * H
-        qf = torch.empty(O, E, device=dev, dtype=torch.float32)
-        one, zero = torch.ones(O, device=dev), torch.zeros(O, device=dev)
-        sc, sh = torch.empty(O, device=dev), torch.empty(O, device=dev)
-        native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
-                           one, zero, zero, one, 0.0, qf, sc, sh)
+        qf, one, zero = _fold_train(variant, K, H, E, D, bilinear_w, query)
         z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
                               write_clamped_vals=True, check_ids=check_ids, flags=flags)
         ctx.save_for_backward(table, bilinear_w, query, values, ids, vals, qf, z)
@@ -57,26 +51,54 @@ class _ArmBlockFn(torch.autograd.Function):
         B, F = vals.shape
         O = K * H
         d_table = torch.zeros_like(table)
-        d_values = torch.zeros(O, F, device=dz.device, dtype=torch.float32)
-        d_qf = torch.zeros(O, E, device=dz.device, dtype=torch.float32)
+        d_values, d_qf = _param_grad_buffers(O, F, E, dz.device)
         native.fused_bwd(B, F, E, O, alpha, n_iter, flags, ids.contiguous(), vals, table.detach(), qf,
                          values.detach().reshape(O, F).contiguous(), z, dz.contiguous(), d_table, d_values, d_qf)
         return _arm_block_grads((variant, K, H, E, D), (bilinear_w, query, values), d_qf, d_table, d_values) + (None, None, None)
+
+
+_CONSTS = {}
+
+
+def _unit_affine(dev, O):
+    """(ones[O], zeros[O], scratch[O], scratch[O]) kept per device and width: the identity BatchNorm affine of the
+    training forward and the unused fold outputs (small per-step allocations and fills add up at batch 4 096)"""
+    key = (str(dev), O)
+    if key not in _CONSTS:
+        _CONSTS[key] = (torch.ones(O, device=dev), torch.zeros(O, device=dev), torch.empty(O, device=dev),
+                        torch.empty(O, device=dev))
+    return _CONSTS[key]
+
+
+def _fold_train(variant, K, H, E, D, bilinear_w, query):
+    dev = query.device
+    O = K * H
+    one, zero, sc, sh = _unit_affine(dev, O)
+    qf = torch.empty(O, E, device=dev, dtype=torch.float32)
+    native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
+                       one, zero, zero, one, 0.0, qf, sc, sh)
+    return qf, one, zero
+
+
+def _param_grad_buffers(O, F, E, dev):
+    """d_values [O,F] and d_q_fold [O,E] as views of ONE zero-filled buffer"""
+    buf = torch.zeros(O * (F + E), device=dev, dtype=torch.float32)
+    return buf[:O * F].view(O, F), buf[O * F:].view(O, E)
 
 
 def _arm_block_grads(ctx_cfg, tensors, d_qf, d_table, d_values):
     """chain rule through the parameter fold (q_fold from bilinear_w and query)"""
     variant, K, H, E, D = ctx_cfg
     bilinear_w, query, values = tensors
-    scale = float(D) ** -0.5
+    d_qf = d_qf * (float(D) ** -0.5)
     if variant == native.ONE_HEAD:                      # q_fold = scale * query @ W,  W = bilinear_w [D,E]
-        d_q = scale * (d_qf @ bilinear_w.t())
-        d_w = scale * (query.t() @ d_qf)
+        d_q = d_qf @ bilinear_w.t()
+        d_w = query.t() @ d_qf
     else:                                               # q_fold[k,o,e] = scale * sum_y W[k,e,y] query[k,o,y]
         g3 = d_qf.view(K, H, E)
-        d_q = scale * torch.einsum("koe,key->koy", g3, bilinear_w)
-        d_w = scale * torch.einsum("koe,koy->key", g3, query)
-    return d_table, d_w, d_q, d_values.view_as(values)
+        d_q = torch.einsum("koe,key->koy", g3, bilinear_w)
+        d_w = torch.einsum("koe,koy->key", g3, query)
+    return d_table, d_w, d_q, d_values.reshape(values.shape)
 
 
 class _ArmBlockBNFn(torch.autograd.Function):
@@ -88,13 +110,7 @@ class _ArmBlockBNFn(torch.autograd.Function):
     def forward(ctx, table, bilinear_w, query, values, bn_weight, bn_bias, ids, vals, cfg, bn_state):
         variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
         running_mean, running_var, momentum, eps = bn_state
-        dev = query.device
-        O = K * H
-        qf = torch.empty(O, E, device=dev, dtype=torch.float32)
-        one, zero = torch.ones(O, device=dev), torch.zeros(O, device=dev)
-        sc, sh = torch.empty(O, device=dev), torch.empty(O, device=dev)
-        native.fold_params(variant, K, H, E, D, bilinear_w.detach().contiguous(), query.detach().contiguous(),
-                           one, zero, zero, one, 0.0, qf, sc, sh)
+        qf, one, zero = _fold_train(variant, K, H, E, D, bilinear_w, query)
         z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
                               write_clamped_vals=True, check_ids=check_ids, flags=flags)
         y, mean, rstd, _, _ = native.bn_forward_train(z, bn_weight.detach(), bn_bias.detach(), running_mean,
@@ -112,8 +128,7 @@ class _ArmBlockBNFn(torch.autograd.Function):
         dy = dy.contiguous()
         d_bnw, d_bnb, cA, cB, cC = native.bn_backward_coef(z, dy, bn_weight.detach(), mean, rstd)
         d_table = torch.zeros_like(table)
-        d_values = torch.zeros(O, F, device=dy.device, dtype=torch.float32)
-        d_qf = torch.zeros(O, E, device=dy.device, dtype=torch.float32)
+        d_values, d_qf = _param_grad_buffers(O, F, E, dy.device)
         native.fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids.contiguous(), vals, table.detach(), qf,
                             values.detach().reshape(O, F).contiguous(), z, dy, cA, cB, cC, d_table, d_values, d_qf)
         d_table, d_w, d_q, d_v = _arm_block_grads((variant, K, H, E, D), (bilinear_w, query, values), d_qf, d_table,

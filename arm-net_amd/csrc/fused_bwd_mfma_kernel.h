@@ -117,8 +117,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const bool dbg_no_scatter = (a.flags & 0x400u) != 0;   // skip the d_table atomics
     const bool dbg_one_pass = (a.flags & 0x2000u) != 0;    // only the first 16-neuron pass
     const bool dbg_hot_rows = (a.flags & 0x200u) != 0;     // fold ids into 1024 rows
+    const bool dbg_no_flush = (a.flags & 0x4000u) != 0;    // skip the block's d_values / d_qfold atomics
 #else
-    constexpr bool dbg_no_scatter = false, dbg_one_pass = false, dbg_hot_rows = false;
+    constexpr bool dbg_no_scatter = false, dbg_one_pass = false, dbg_hot_rows = false, dbg_no_flush = false;
 #endif
 
     // ---- block prologue: parameters of this neuron slice, zeroed accumulators -------------------------
@@ -579,6 +580,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             for (int r = 0; r < 4; ++r) atomicAdd(dq_row + 16 * eb + r, dqacc[nt][eb][r]);
     }
     __syncthreads();
+    if (dbg_no_flush) return;
     for (int i = threadIdx.x; i < O * F; i += 256) {
         const int o = i / F, f = i - o * F;
         unsafeAtomicAdd(a.d_values + i, acc_dv[o * FP + f]);
