@@ -49,7 +49,10 @@ inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_s
 }
 
 constexpr int kNewtonMaxIter = 40;
-constexpr float kNewtonTol = 2e-7f;   // stop once sum(p) - 1 <= tol (a few fp32 ulps of 1)
+#ifndef ARMNET_NEWTON_TOL
+#define ARMNET_NEWTON_TOL 2e-7f
+#endif
+constexpr float kNewtonTol = ARMNET_NEWTON_TOL;   // stop once sum(p) - 1 <= tol (a few fp32 ulps of 1)
 
 // thread-local record of the last HIP failure (armnet_last_hip_error)
 void set_hip_error(hipError_t e, const char* where);
