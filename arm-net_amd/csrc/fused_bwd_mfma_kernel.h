@@ -25,12 +25,12 @@
 
 namespace armnet {
 
-constexpr int kBwdSlice = 32;     // neurons per launch = 2 passes: the d_values / d_qfold accumulators of a slice
-                                  // stay in registers over all samples of a wave (LDS float atomics from 4 waves on
-                                  // the same addresses cost more than the rest of the kernel: measured 888 -> 368 us)
-constexpr int kBwdNT = kBwdSlice / 16;
-// nemb = 64: one pass per launch (the per-wave accumulators of two passes do not fit beside the dx tiles)
-constexpr int bwd_passes(int E) { return E >= 64 ? 1 : kBwdNT; }
+// Passes (16 neurons each) per launch: the d_values / d_qfold accumulators of a launch's neuron slice stay in
+// registers over all samples of a wave (LDS float atomics from 4 waves on the same addresses cost more than the rest
+// of the kernel: measured 888 -> 368 us), so the slice is what the register file holds beside the dx tiles:
+// 4 passes for nemb <= 16, 2 for nemb <= 32, 1 for nemb = 64.  Wider blocks run as several launches, each of which
+// re-stages the rows and scatters its part of dx.
+constexpr int bwd_passes(int E) { return E >= 64 ? 1 : E > 16 ? 2 : 4; }
 
 template <int E, int NQ, int MODE, int SRC, int CB>
 __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
@@ -64,9 +64,10 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     float* p_bq = lds_all + 4 * WAVE_FLOATS;  // [NT][EB][64] f32x4   q_fold as the B operand of MFMA #1
     float* p_vv = p_bq + NT * EB * 64 * 4;    // [NT][NP][64] f32x2   values in the C layout
     float* qfl = p_vv + NT * NP * 64 * 2;     // [OP][ES]            q_fold, plain (B operand of MFMA #5)
-    float* acc_dv = qfl + OP * ES;            // [OP][FP]
+    float* p_cf = qfl + OP * ES;              // [OP] f32x4 {A, B, C, -}: dz = A * dz_in + C * z + B (BatchNorm backward)
+    // block accumulators of the final flush: they ALIAS the wave-private regions (used only after every wave is done)
+    float* acc_dv = lds_all;                  // [OP][FP]
     float* acc_dq = acc_dv + OP * FP;         // [OP][E]
-    float* p_cf = acc_dq + OP * E;            // [OP] f32x4 {A, B, C, -}: dz = A * dz_in + C * z + B (BatchNorm backward)
 
     const int Bi = (int)a.B;
     const int nwaves = (int)gridDim.x * 4;
@@ -146,7 +147,6 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         const int o = i / ES, e = i - o * ES;
         qfl[i] = (o < O && e < Er) ? a.q_fold[(size_t)o * Er + e] : 0.f;
     }
-    for (int i = threadIdx.x; i < OP * (FP + E); i += 256) acc_dv[i] = 0.f;     // acc_dv and acc_dq are contiguous
     for (int i = threadIdx.x; i < OP; i += 256) {
         const bool on = a.bn_a != nullptr && i < O;
         *reinterpret_cast<f32x4*>(p_cf + 4 * i) = f32x4{on ? a.bn_a[i] : 1.0f, on ? a.bn_b[i] : 0.f, on ? a.bn_c[i] : 0.f, 0.f};
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const int npass = dbg_one_pass ? 1 : NT;
     // prefetch depth by register budget: 2 = rows of the next sample + ids of the one after + dz/z one pass ahead
     // (nemb <= 16), 1 = ids of the next sample + dz/z one pass ahead (nemb <= 32), 0 = nothing carried (nemb = 64)
-    constexpr int PF = E <= 16 ? 2 : (E <= 32 && NQ <= 8) ? 1 : 0;
+    constexpr int PF = (E <= 16 && NQ <= 6) ? 2 : (E <= 16 || (E <= 32 && NQ <= 8)) ? 1 : 0;
     if (b_first < Bi) {
         if constexpr (PF == 2) {
             fetch_ids(b_first, idC, vC);
@@ -544,6 +544,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                 }
             }
             wave_lds_fence();
+            // keep the unrolled passes apart: without this the scheduler hoists the next passes' operand loads over
+            // the current one and the four passes' live ranges no longer fit the register file
+            __builtin_amdgcn_sched_barrier(0);
 #undef XG
 #undef XP_GET
 #undef XP_SET
@@ -567,6 +570,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             }
     }
     // ---- wave accumulators -> block accumulators (LDS atomics, once per wave) -> global ------------------------
+    __syncthreads();                                                             // every wave is done with its region
+    for (int i = threadIdx.x; i < OP * (FP + E); i += 256) acc_dv[i] = 0.f;     // acc_dv and acc_dq are contiguous
+    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
         if (nt >= NT) break;
@@ -597,7 +603,8 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 2 * 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
     const int NT = (a.O + 15) / 16, OP = NT * 16;
     size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
-                  (size_t)OP * (E + 4) + (size_t)OP * (4 * NQ) + (size_t)OP * E + (size_t)OP * 4) * sizeof(float);
+                  (size_t)OP * (E + 4) + (size_t)OP * 4) * sizeof(float);
+    if ((size_t)OP * (4 * NQ + E) > (size_t)4 * WAVE_FLOATS) return ARMNET_ERR_UNSUPPORTED;    // the aliased accumulators
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
     if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
     int per_cu = (int)(160 * 1024 / lds);
