@@ -87,8 +87,7 @@ def embedding_forward(ids, vals, table, check_ids=True):
     return out
 
 
-def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0):
-    """utils/entmax.py:134 — alpha-entmax over `dim` (softmax when alpha == 1)."""
+def _entmax_raw(X, alpha, dim, n_iter, ensure_sum_one, flags):
     _require_cuda(X, "X")
     if X.dtype != torch.float32:
         raise native.ArmnetNativeError(f"entmax: float32 only, got {X.dtype}")
@@ -100,3 +99,35 @@ def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0
     if Xt.numel():
         native.entmax(Xt.numel() // d, d, float(alpha), n_iter, ensure_sum_one, flags, Xt, P)
     return P.movedim(-1, dim) if dim != nd - 1 else P
+
+
+class _EntmaxFn(torch.autograd.Function):
+    """forward: armnet_entmax_f32; backward: the Jacobian-vector product of utils/entmax.py:70-80 on the saved output
+    (softmax's for alpha == 1).  The gradient with respect to alpha (entmax.py:82-98) is not provided: alpha is a
+    float hyper-parameter on every call path of the reference's models."""
+
+    @staticmethod
+    def forward(ctx, X, alpha, dim, n_iter, ensure_sum_one, flags):
+        Y = _entmax_raw(X, alpha, dim, n_iter, ensure_sum_one, flags)
+        ctx.save_for_backward(Y)
+        ctx.alpha, ctx.dim = float(alpha), dim
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        Y, = ctx.saved_tensors
+        if ctx.alpha == 1.0:
+            dX = Y * (dY - (Y * dY).sum(ctx.dim, keepdim=True))
+        else:
+            gppr = torch.where(Y > 0, Y ** (2.0 - ctx.alpha), torch.zeros((), device=Y.device, dtype=Y.dtype))
+            dX = dY * gppr
+            q = dX.sum(ctx.dim, keepdim=True) / gppr.sum(ctx.dim, keepdim=True)
+            dX = dX - q * gppr
+        return dX, None, None, None, None, None
+
+
+def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0):
+    """utils/entmax.py:134 — alpha-entmax over `dim` (softmax when alpha == 1); differentiable in X."""
+    if torch.is_grad_enabled() and X.requires_grad:
+        return _EntmaxFn.apply(X, alpha, dim, n_iter, ensure_sum_one, flags)
+    return _entmax_raw(X, alpha, dim, n_iter, ensure_sum_one, flags)

@@ -4,8 +4,8 @@
 keep the reference's names, argument meaning and defaults (entmax.py:134,238-275) and dispatch to
 armnet_entmax_f32.  With n_iter >= 24 and alpha <= 2 the HIP kernel solves the same threshold root by
 Newton/Michelot iterations (result within ~1e-6 of the 50-step bisection); otherwise it runs the
-reference's bisection step for step.  Forward only (the custom backward, entmax.py:70-100, is a
-"next" row in SURVEY.md §8f).
+reference's bisection step for step.  Differentiable in X (the Jacobian-vector product of
+entmax.py:70-80 on the saved output); the gradient with respect to alpha (entmax.py:82-98) is not provided.
 """
 import torch.nn as nn
 

@@ -286,6 +286,7 @@ def main():
     grad_case("h1_grad_1h_ens_a2.0_train", "1h", base(22, 128, 32, 2.0, 32, ensemble=True, mlp_nhid=16, deep_nhid=16),
               16, 84, True)
     entmax_cases()
+    entmax_grad_cases()
     run_sh_cases()
 
 
@@ -313,8 +314,33 @@ def run_sh_cases():
                5, 99, "stress")
 
 
+def entmax_grad_cases():
+    """G6b: backward of the sparse map alone (utils/entmax.py:70-80), dX for a random dY."""
+    from utils.entmax import entmax_bisect
+    gen = torch.Generator().manual_seed(78)
+    out = {}
+    for alpha in (1.5, 1.7, 2.0, 2.5):
+        for scale in (0.3, 2.0):
+            X = (torch.randn(6, 5, 39, generator=gen) * scale).requires_grad_(True)
+            dY = torch.randn(6, 5, 39, generator=gen)
+            Y = entmax_bisect(X, alpha=alpha, dim=-1)
+            Y.backward(dY)
+            k = f"a{alpha}_s{scale}"
+            out["X/" + k], out["dY/" + k], out["Y/" + k], out["dX/" + k] = X.detach().numpy(), dY.numpy(), Y.detach().numpy(), X.grad.numpy()
+    # a middle dim, like the reference's dim argument allows
+    X = torch.randn(4, 13, 3, generator=gen).requires_grad_(True)
+    dY = torch.randn(4, 13, 3, generator=gen)
+    Y = entmax_bisect(X, alpha=1.5, dim=1)
+    Y.backward(dY)
+    out["X/dim1"], out["dY/dim1"], out["Y/dim1"], out["dX/dim1"] = X.detach().numpy(), dY.numpy(), Y.detach().numpy(), X.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "g6_entmax_grad.npz"), **out)
+    print("g6_entmax_grad", len(out) // 4, "cases")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others
+    if len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
+        entmax_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others
         run_sh_cases()
     else:
         main()

@@ -189,3 +189,26 @@ def test_graphed_train_step_equals_eager_steps():
             continue
         a, b = s0[k].float(), s1[k].float()
         assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3), k
+
+
+def test_entmax_backward_matches_reference_gradients():
+    """utils.entmax.entmax_bisect(...).backward(dY) against dX captured from the reference (entmax.py:70-80),
+    including alpha = 2.5 (forward by the literal bisection) and a middle `dim`."""
+    import os
+    from golden_util import GOLDEN
+    from utils.entmax import entmax_bisect, EntmaxBisect
+    z = np.load(os.path.join(GOLDEN, "g6_entmax_grad.npz"))
+    keys = sorted(k[2:] for k in z.files if k.startswith("X/"))
+    assert len(keys) == 9
+    for k in keys:
+        X = torch.from_numpy(z["X/" + k]).to(DEV).requires_grad_(True)
+        dY = torch.from_numpy(z["dY/" + k]).to(DEV)
+        if k == "dim1":
+            Y = entmax_bisect(X, alpha=1.5, dim=1)
+        else:
+            alpha = float(k.split("_")[0][1:])
+            Y = EntmaxBisect(alpha=alpha, dim=-1)(X)
+        Y.backward(dY)
+        assert float((Y.detach().cpu() - torch.from_numpy(z["Y/" + k])).abs().max()) <= 2e-6, k
+        ref = torch.from_numpy(z["dX/" + k])
+        assert float((X.grad.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), k
