@@ -56,6 +56,7 @@ int armnet_fused_kernel_kind(int F, int E, int O, float alpha, int n_iter, uint3
 
 static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (a.B < 0 || a.F <= 0 || a.E <= 0 || a.O <= 0 || n_iter < 0) return ARMNET_ERR_BAD_ARG;
+    if (a.B == 0) return ARMNET_OK;                       // empty batch: pointers may be null
     if (!a.vals || !a.q_fold || !a.values || !a.bn_scale || !a.bn_shift || !a.out) return ARMNET_ERR_BAD_ARG;
     if (!(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     a.cfg = make_sparse_cfg(alpha, n_iter, a.F, 1, a.flags);
@@ -70,6 +71,7 @@ int armnet_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter
                          const void* ids, int id_type, float* vals, const float* table, int64_t nfeat,
                          const float* q_fold, const float* values, const float* bn_scale,
                          const float* bn_shift, float* out, int32_t* id_status, void* stream) {
+    if (B == 0 && F > 0 && E > 0 && O > 0) return ARMNET_OK;
     if (!ids || !table || nfeat <= 0) return ARMNET_ERR_BAD_ARG;
     if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
@@ -86,6 +88,7 @@ int armnet_fused_fwd_from_rows_f32(int64_t B, int F, int E, int O, float alpha, 
                                    const float* rows, float* vals, const float* q_fold,
                                    const float* values, const float* bn_scale, const float* bn_shift,
                                    float* out, void* stream) {
+    if (B == 0 && F > 0 && E > 0 && O > 0) return ARMNET_OK;
     if (!rows) return ARMNET_ERR_BAD_ARG;
     FusedArgs a{};
     a.B = B; a.F = F; a.E = E; a.O = O;

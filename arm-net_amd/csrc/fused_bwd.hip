@@ -177,6 +177,7 @@ static int fused_bwd_impl(int64_t B, int F, int E, int O, float alpha, int n_ite
                           const float* values, const float* z, const float* dz, const float* bn_a, const float* bn_b,
                           const float* bn_c, float* d_table, float* d_values, float* d_qfold, void* stream) {
     if (B < 0 || F <= 0 || E <= 0 || O <= 0 || n_iter < 0 || nfeat <= 0) return ARMNET_ERR_BAD_ARG;
+    if (B == 0) return ARMNET_OK;
     if (!ids || !vals || !table || !q_fold || !values || !z || !dz || !d_table || !d_values || !d_qfold)
         return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;

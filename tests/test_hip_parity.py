@@ -396,3 +396,35 @@ def test_matrix_core_kernel_agrees_with_generic_kernel_for_every_nfield(E):
                 assert err <= TOL, f"nfield={F} nemb={E} neurons={O} alpha={alpha}: {err}"
                 worst, n = max(worst, err), n + 1
     assert n == 48 * 9
+
+
+def test_misaligned_buffers_and_empty_batch():
+    """a table / output that is only 4-byte aligned cannot take the matrix-core kernel's 16-byte accesses: the ABI
+    must fall back to the shape-agnostic kernel (same result), and an empty batch is a no-op"""
+    from armnet_hip import native
+    F, E, O, alpha, B, nfeat = 39, 16, 32, 2.0, 100, 211
+    g = torch.Generator().manual_seed(4)
+    big = (torch.rand(nfeat * E + 1, generator=g) * 1.6 - 0.8).to(DEV)
+    table_off = big[1:].view(nfeat, E)                    # storage offset of one float
+    table = table_off.clone()                             # same values, allocator-aligned
+    assert table_off.data_ptr() % 16 == 4
+    qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+    values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+    sc, sh = (torch.rand(O, generator=g) + 0.5).to(DEV), torch.randn(O, generator=g).to(DEV)
+    want = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, sc, sh, want)
+    got = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd(B, F, E, O, alpha, 50, 0, ids, vals, table_off, qf, values, sc, sh, got)
+    assert _rel_err(got.cpu().numpy(), want.cpu().numpy()) <= TOL
+    out_big = torch.zeros(B * O * E + 1, device=DEV)
+    out_off = out_big[1:].view(B, O, E)
+    native.fused_fwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, sc, sh, out_off)
+    assert _rel_err(out_off.cpu().numpy(), want.cpu().numpy()) <= TOL
+    # empty batch: nothing is launched, nothing is touched
+    e_ids = torch.empty(0, F, dtype=torch.int64, device=DEV)
+    e_vals = torch.empty(0, F, device=DEV)
+    e_out = torch.empty(0, O, E, device=DEV)
+    native.fused_fwd(0, F, E, O, alpha, 50, 0, e_ids, e_vals, table, qf, values, sc, sh, e_out)
+    torch.cuda.synchronize()
