@@ -66,6 +66,9 @@ class RowShardedTable:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ops = ops if ops is not None else HipShardOps()
+        # gloo has no device all-to-all: with that backend (debugging, the 2-processes-on-1-GPU test) the two exchanges
+        # are staged through host memory; RCCL ("nccl") exchanges device buffers directly
+        self._via_host = bool(dist.is_initialized() and dist.get_backend(group) == "gloo" and table_local.is_cuda)
         expect = (self.nfeat - self.rank + self.world - 1) // self.world
         if table_local.shape[0] != expect:
             raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
@@ -82,18 +85,30 @@ class RowShardedTable:
             n_send = int(counts.sum().item()) if dedup else n
             return self.ops.gather(send_local[:n_send], self.table_local), perm
         # split matrix: row q = what rank q sends to each owner
-        allc = torch.empty(R * R, device=counts.device, dtype=torch.int32)
-        dist.all_gather_into_tensor(allc, counts, group=self.group)
+        if self._via_host:
+            allc = torch.empty(R * R, dtype=torch.int32)
+            dist.all_gather_into_tensor(allc, counts.cpu(), group=self.group)
+        else:
+            allc = torch.empty(R * R, device=counts.device, dtype=torch.int32)
+            dist.all_gather_into_tensor(allc, counts, group=self.group)
         m = allc.view(R, R).cpu()                      # the one host sync of the step
         send_counts = m[self.rank].tolist()
         recv_counts = m[:, self.rank].tolist()
         recv_idx = torch.empty(sum(recv_counts), device=flat.device, dtype=torch.int32)
         n_send = sum(send_counts)                      # == n without de-duplication
-        dist.all_to_all_single(recv_idx, send_local[:n_send], recv_counts, send_counts, group=self.group)
+        self._all_to_all(recv_idx, send_local[:n_send], recv_counts, send_counts)
         rows_out = self.ops.gather(recv_idx, self.table_local)
         rows_in = torch.empty(n_send, E, device=flat.device, dtype=torch.float32)
-        dist.all_to_all_single(rows_in, rows_out, send_counts, recv_counts, group=self.group)
+        self._all_to_all(rows_in, rows_out, send_counts, recv_counts)
         return rows_in, perm
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if self._via_host:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
 
 def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,

@@ -1,0 +1,60 @@
+"""The row-sharded lookup with the REAL device kernels at world size 2 on one GPU: two processes share cuda:0,
+the exchanges go through gloo (staged through host memory, sharded.py), everything else — HIP routing with and
+without de-duplication, owner-side gather, the fused kernel over (received rows, perm) — is the product path.
+Each rank's result must be bit-equal to the replicated-table result for its own samples."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, dedup, q):
+    for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from golden_util import load
+        from model_util import build_model
+        dev = "cuda:0"
+        meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
+        c = meta["ctor"]
+        g = torch.Generator().manual_seed(50 + rank)
+        B = 333 + 7 * rank                                    # ragged: the ranks hold different batch sizes
+        ids = torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g)
+        ids[0, :3] = torch.tensor([0, c["nfeat"] - 1, 1])     # boundary rows, both owners
+        ids[1, :] = ids[1, 0]                                 # duplicates in one sample
+        vals = torch.rand(B, c["nfield"], generator=g)
+        m = build_model(meta, sd, dev)
+        with torch.no_grad():
+            want = m.arm_block(ids.to(dev), vals.clone().to(dev))
+            m.shard_embedding()
+            m._shard.dedup = dedup
+            assert m._shard.world == world and m._shard._via_host
+            got = m.arm_block(ids.to(dev), vals.clone().to(dev))
+        q.put((rank, bool(torch.equal(got, want)), float((got - want).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29621 + int(dedup)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, f"rank {rank}: sharded result differs from replicated by {err}"
