@@ -3,11 +3,9 @@
 
 namespace armnet {
 
-// nemb even and <= 64 (8-byte staging chunks only up to 16), nfield <= 48; any neuron count (slices)
+// nemb 2 or 4..64 (any, odd too), nfield <= 48; any neuron count (slices)
 bool fused_bwd_mfma_supports(int F, int E, int O) {
-    if (E < 2 || E > 64 || (E & 1) || O < 1 || F < 1 || F > 48) return false;
-    if (E > 16 && E % 4 != 0) return false;
-    return true;
+    return !(E < 2 || E > 64 || E == 3 || O < 1 || F < 1 || F > 48);
 }
 
 int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
@@ -15,9 +13,7 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
     if (!fused_bwd_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
-    const bool c16 = (a.E % 4 == 0);
-    if (((uintptr_t)a.table % (c16 ? 16 : 8))) return ARMNET_ERR_UNSUPPORTED;
-    if (a.E % 16 == 0 && (((uintptr_t)a.z % 16) || ((uintptr_t)a.dz % 16))) return ARMNET_ERR_UNSUPPORTED;
+    const bool c16 = (a.E >= 4);     // 16-byte staging chunks; rows, z and dz need only their natural 4-byte alignment
     // slices of 32 (nemb = 64: 16) neurons: each re-stages the rows and adds its part of dx to the table gradient
     const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64);
     for (int o0 = 0; o0 < a.O; o0 += slice) {

@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     constexpr int WAVE_FLOATS = XT + RED + 2 * TW + DSL + IDV;
     static_assert(E % 16 == 0 && ROWS % RPI == 0 && NQ % 2 == 0 && (CB == 16 || CB == 8), "shape");
     using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
+    using RowTU = typename std::conditional<CB == 16, f32x4u, f32x2u>::type;     // as read from global memory
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -74,7 +75,10 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 
     // ---- staging geometry (one sample per wave): fused_mfma_kernel.h with SPW = 1 -------------------
     const int chunk = lane % CH;
-    const bool chunk_ok = (chunk + 1) * CF <= Er;
+    // full / partial (read from the row's last 16 bytes, rotated into place) / padding chunks: fused_mfma_kernel.h
+    const int rem = (CB == 16) ? (Er & 3) : 0;
+    const bool chunk_part = (CB == 16) && rem != 0 && chunk == (Er >> 2);
+    const bool chunk_ok = (chunk + 1) * CF <= Er || chunk_part;
     int fld[NI];         // field of the row this lane stages in instruction n (0 for a pad row)
     bool pad[NI];
 #pragma unroll
@@ -90,7 +94,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const bool two_pad = F <= 4 * (NQ - 1);
     const uint32_t id_max = (uint32_t)a.nfeat - 1u;
     const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
-    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(a.table) + chunk * CB
+    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(a.table) + (chunk_part ? (Er - 4) * 4 : chunk * CB)
                                     : reinterpret_cast<const char*>(kZeroRow);
     constexpr int XQ = 4 * NTILE - NQ;
     constexpr int NZ = ((7 + 4 * XQ) * (E / 4) + 63) / 64;
@@ -198,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     };
     auto fetch_rows = [&]() {
 #pragma unroll
-        for (int n = 0; n < NI; ++n) rwC[n] = *reinterpret_cast<const RowT*>(row_base + (size_t)idC[n] * row_bytes);
+        for (int n = 0; n < NI; ++n) rwC[n] = *reinterpret_cast<const RowTU*>(row_base + (size_t)idC[n] * row_bytes);
     };
     auto fetch_zd = [&](int bb, int nt) {
         const int o = 16 * nt + c;
@@ -208,9 +212,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             zN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
             dN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (o < O) {
-                if (full_rows) {
-                    zN[eb] = *reinterpret_cast<const f32x4*>(a.z + zo + 16 * eb);
-                    dN[eb] = *reinterpret_cast<const f32x4*>(a.dz + zo + 16 * eb);
+                if (full_rows || 16 * eb + 4 * g + 4 <= Er) {
+                    zN[eb] = *reinterpret_cast<const f32x4u*>(a.z + zo + 16 * eb);
+                    dN[eb] = *reinterpret_cast<const f32x4u*>(a.dz + zo + 16 * eb);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -257,7 +261,15 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             const int row = n * RPI + lane / CH;
-            *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = rwC[n] * vC[n];
+            RowT r = rwC[n] * vC[n];
+            if constexpr (CB == 16) {
+                if (rem != 0) {                                         // kernel-uniform
+                    const f32x4 t = rem == 1 ? f32x4{r[3], 0.f, 0.f, 0.f}
+                                  : rem == 2 ? f32x4{r[2], r[3], 0.f, 0.f} : f32x4{r[1], r[2], r[3], 0.f};
+                    r = chunk_part ? t : r;
+                }
+            }
+            *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = r;
             if (chunk == 0) {
                 idl[row] = pad[n] ? 0xffffffffu : idC[n];
                 vll[row] = vC[n];

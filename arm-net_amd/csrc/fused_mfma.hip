@@ -3,12 +3,10 @@
 
 namespace armnet {
 
-// nemb even, <= 64; nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
+// nemb 2 or 4..64 (any, odd too); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
 bool fused_mfma_supports(int F, int E, int O) {
-    if (E < 2 || E > 64 || (E & 1) || O < 1 || O > 1024 || F < 1 || F > 48) return false;
+    if (E < 2 || E > 64 || E == 3 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
     const int nq = (((F + 3) / 4) + 1) & ~1;
-    if (E > 32 && E % 4 != 0) return false;               // the nemb=64 family has 16-byte chunks only
-    if (E > 16 && E <= 32 && E % 4 != 0) return false;    // 8-byte chunks are instantiated for nemb <= 16
     // LDS of one block (same formula as launch_one): 4 wave tiles + the lane-ready parameters of one slice
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
     const int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
@@ -23,10 +21,9 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B * a.F >= ((int64_t)1 << 29)) return ARMNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into ids/vals
     if (!fused_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;            // quarter-steps per sample, rounded up to even
-    const bool c16 = (a.E % 4 == 0);
-    const uintptr_t src = (uintptr_t)(a.rows ? a.rows : a.table);
-    if (((uintptr_t)a.q_fold % 16) || (src % (c16 ? 16 : 8))) return ARMNET_ERR_UNSUPPORTED;
-    if (a.E % 16 == 0 && ((uintptr_t)a.out % 16)) return ARMNET_ERR_UNSUPPORTED;
+    // 16-byte staging chunks for every nemb >= 4 (rows need only their natural 4-byte alignment: the partial last
+    // chunk is read from the row's last 16 bytes); the 8-byte family serves nemb = 2
+    const bool c16 = (a.E >= 4);
     // > 256 neurons: the lane-ready parameter copies no longer fit in LDS next to the tiles -> slices of 256
     // (each slice re-gathers the rows; the in-place clamp is idempotent)
     for (int o0 = 0; o0 < a.O; o0 += 256) {

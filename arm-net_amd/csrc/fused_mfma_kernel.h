@@ -10,7 +10,7 @@
 // One WAVE owns a group of SPW samples at a time and never talks to another wave (wave-private
 // LDS tile, no block barrier after the prologue).  Per group:
 //
-//   stage     coalesced chunk loads (16 B, or 8 B when nemb % 4 != 0) of the F embedding rows of each sample
+//   stage     coalesced 16-byte chunk loads (4-byte aligned: any nemb >= 4) of the F embedding rows of each sample
 //             (adjacent lanes share a row), scaled by clamp(value), written to the wave's LDS tile whose rows
 //             are zero-padded to E = 16/32/64 floats.  Rows of the NEXT group are already in flight
 //             (registers) and the raw ids of the group after that are being fetched.
@@ -29,7 +29,7 @@
 //   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte
 //             store per lane when nemb is a multiple of 16 (element stores otherwise).
 //
-// Shapes: nemb even and <= 64, nfield <= 48, nhead*nhid <= 256 (neurons padded to 16 per pass).
+// Shapes: nemb 2 or 4..64, nfield <= 48, nhead*nhid <= 256 per launch (neurons padded to 16 per pass).
 #pragma once
 #include <stdlib.h>
 
@@ -44,6 +44,10 @@ static __device__ float kZeroRow[4] = {0.f, 0.f, 0.f, 0.f};   // not const: keep
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 4-byte aligned views for global memory: gfx950 runs in unaligned access mode, so these still compile to ONE
+// global_load/store_dwordx4 / dwordx2 (rows of nemb floats are only 4-byte aligned when nemb is odd)
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+typedef f32x2 f32x2u __attribute__((aligned(4)));
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 
@@ -105,7 +109,7 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 
 // E = nemb padded to 16/32/64; NQ = quarter-steps per sample (even); SPW samples per wave-group;
 // SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows; WPS = waves/SIMD the register budget targets;
-// CB = bytes per staging lane (16, or 8 when nemb % 4 != 0)
+// CB = bytes per staging lane (16; the 8-byte family serves nemb = 2)
 template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int CB>
 __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
@@ -123,6 +127,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0 && NQ % 2 == 0 && SPW <= 2 &&
                   (CB == 16 || CB == 8), "shape");
     using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
+    using RowTU = typename std::conditional<CB == 16, f32x4u, f32x2u>::type;     // as read from global memory
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -147,7 +152,11 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
-    const bool chunk_ok = (chunk + 1) * CF <= Er;        // chunk lies inside the real row
+    // a chunk is full (inside the row), partial (CB = 16 only: the row ends inside it; it is loaded from the LAST 16
+    // bytes of the row instead and rotated into place) or padding (reads zeros)
+    const int rem = (CB == 16) ? (Er & 3) : 0;           // floats of the partial chunk (0: there is none)
+    const bool chunk_part = (CB == 16) && rem != 0 && chunk == (Er >> 2);
+    const bool chunk_ok = (chunk + 1) * CF <= Er || chunk_part;
     uint32_t off4[NI];   // 4 * (s*F + f) of the row this lane stages in instruction n (0 for a pad row)
     bool pad[NI];        // pad row (field >= nfield, or a quarter-step past the group): zeroed after staging
 #pragma unroll
@@ -181,7 +190,8 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const uint32_t id_max = (uint32_t)a.nfeat - 1u;
     // lanes whose chunk lies in the zero padding of a row (nemb < E) read zeros: lane-constant base and stride
     const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
-    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) + chunk * CB
+    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) +
+                                          (chunk_part ? (Er - 4) * 4 : chunk * CB)
                                     : reinterpret_cast<const char*>(kZeroRow);
     // pad rows are staged like any other (their lanes re-read element 0 of the group) and then overwritten with
     // zeros, so that a non-finite embedding of one sample cannot leak into its group neighbour through 0 * NaN.
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 const uint32_t id = min(raw_lo[n], id_max) & id_mask;   // memory-safe even when unchecked
                 src = row_base + (size_t)id * row_bytes;
             }
-            rows_cur[n] = *reinterpret_cast<const RowT*>(src);
+            rows_cur[n] = *reinterpret_cast<const RowTU*>(src);
         }
     };
 
@@ -326,7 +336,15 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             v = (vraw != vraw) ? vraw : v;
             vcl[n] = v;
             changed |= (v != vraw) && !pad[n];
-            const RowT r = rows_cur[n] * v;
+            RowT r = rows_cur[n] * v;
+            if constexpr (CB == 16) {
+                if (rem != 0) {                                         // kernel-uniform
+                    // partial chunk: the lane holds the row's last 4 floats; its own are the last `rem` of them
+                    const f32x4 t = rem == 1 ? f32x4{r[3], 0.f, 0.f, 0.f}
+                                  : rem == 2 ? f32x4{r[2], r[3], 0.f, 0.f} : f32x4{r[1], r[2], r[3], 0.f};
+                    r = chunk_part ? t : r;
+                }
+            }
             const int row = n * RPI + lane / CH;
             *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = r;
         }
@@ -575,14 +593,19 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                             const f32x2 ehi = {__builtin_amdgcn_exp2f(zhi[0]), __builtin_amdgcn_exp2f(zhi[1])};
                             const f32x2 vlo = __builtin_elementwise_fma(elo, bn0, bn1);
                             const f32x2 vhi = __builtin_elementwise_fma(ehi, bn0, bn1);
+                            const int e = 16 * eb + 4 * g;
                             if (fast_store) {
-                                *reinterpret_cast<f32x4*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
+                                *reinterpret_cast<f32x4u*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
                             } else if (o_ok) {
-                                const int e = 16 * eb + 4 * g;
-                                if (e + 0 < Er) dst[16 * eb + 0] = vlo[0];
-                                if (e + 1 < Er) dst[16 * eb + 1] = vlo[1];
-                                if (e + 2 < Er) dst[16 * eb + 2] = vhi[0];
-                                if (e + 3 < Er) dst[16 * eb + 3] = vhi[1];
+                                if (e + 4 <= Er) {
+                                    *reinterpret_cast<f32x4u*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
+                                } else if (e + 2 == Er) {
+                                    *reinterpret_cast<f32x2u*>(dst + 16 * eb) = vlo;
+                                } else {
+                                    if (e + 0 < Er) dst[16 * eb + 0] = vlo[0];
+                                    if (e + 1 < Er) dst[16 * eb + 1] = vlo[1];
+                                    if (e + 2 < Er) dst[16 * eb + 2] = vhi[0];
+                                }
                             }
                         }
                     }
