@@ -3,9 +3,9 @@
 
 namespace armnet {
 
-// nemb 2 or 4..64 (any, odd too), nfield <= 48; any neuron count (slices)
+// nemb 4..64 (any, odd too), nfield <= 48; any neuron count (slices)
 bool fused_bwd_mfma_supports(int F, int E, int O) {
-    return !(E < 2 || E > 64 || E == 3 || O < 1 || F < 1 || F > 48);
+    return !(E < 4 || E > 64 || O < 1 || F < 1 || F > 48);
 }
 
 int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
@@ -13,7 +13,6 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
     if (!fused_bwd_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
-    const bool c16 = (a.E >= 4);     // 16-byte staging chunks; rows, z and dz need only their natural 4-byte alignment
     // slices of 32 (nemb = 64: 16) neurons: each re-stages the rows and adds its part of dx to the table gradient
     const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64);
     for (int o0 = 0; o0 < a.O; o0 += slice) {
@@ -28,9 +27,9 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
         s.d_values = a.d_values + (size_t)o0 * a.F;
         s.d_qfold = a.d_qfold + (size_t)o0 * a.E;
         int rc;
-        if (a.E <= 16) rc = c16 ? launch_bwd_mfma_e16_c16(s, nq, st) : launch_bwd_mfma_e16_c8(s, nq, st);
-        else if (a.E <= 32) rc = launch_bwd_mfma_e32_c16(s, nq, st);
-        else rc = launch_bwd_mfma_e64_c16(s, nq, st);
+        if (a.E <= 16) rc = launch_bwd_mfma_e16(s, nq, st);
+        else if (a.E <= 32) rc = launch_bwd_mfma_e32(s, nq, st);
+        else rc = launch_bwd_mfma_e64(s, nq, st);
         if (rc != ARMNET_OK) return rc;
     }
     return ARMNET_OK;

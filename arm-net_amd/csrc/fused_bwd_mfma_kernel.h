@@ -32,20 +32,20 @@ namespace armnet {
 // re-stages the rows and scatters its part of dx.
 constexpr int bwd_passes(int E) { return E >= 64 ? 1 : E > 16 ? 2 : 4; }
 
-template <int E, int NQ, int MODE, int SRC, int CB>
+template <int E, int NQ, int MODE, int SRC>
 __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
     constexpr int ROWS = NTILE * 16;
     constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
-    constexpr int CF = CB / 4, CH = E / CF, RPI = 64 / CH, NI = ROWS / RPI;
+    constexpr int CF = 4, CH = E / CF, RPI = 64 / CH, NI = ROWS / RPI;     // 16-byte staging chunks
     constexpr int EB = E / 16, NP = NQ / 2;
     constexpr int RS = ROWS + 4;              // row stride of the transposing buffers
     constexpr int FP = 4 * NQ;                // nfield padded
     constexpr int XT = ROWS * ES, RED = 128, TW = 16 * RS, DSL = 16 * ES, IDV = 2 * ROWS;
     constexpr int WAVE_FLOATS = XT + RED + 2 * TW + DSL + IDV;
-    static_assert(E % 16 == 0 && ROWS % RPI == 0 && NQ % 2 == 0 && (CB == 16 || CB == 8), "shape");
-    using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
-    using RowTU = typename std::conditional<CB == 16, f32x4u, f32x2u>::type;     // as read from global memory
+    static_assert(E % 16 == 0 && ROWS % RPI == 0 && NQ % 2 == 0, "shape");
+    using RowT = f32x4;
+    using RowTU = f32x4u;                     // as read from global memory
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     // ---- staging geometry (one sample per wave): fused_mfma_kernel.h with SPW = 1 -------------------
     const int chunk = lane % CH;
     // full / partial (read from the row's last 16 bytes, rotated into place) / padding chunks: fused_mfma_kernel.h
-    const int rem = (CB == 16) ? (Er & 3) : 0;
-    const bool chunk_part = (CB == 16) && rem != 0 && chunk == (Er >> 2);
+    const int rem = Er & 3;
+    const bool chunk_part = rem != 0 && chunk == (Er >> 2);
     const bool chunk_ok = (chunk + 1) * CF <= Er || chunk_part;
     int fld[NI];         // field of the row this lane stages in instruction n (0 for a pad row)
     bool pad[NI];
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const bool two_pad = F <= 4 * (NQ - 1);
     const uint32_t id_max = (uint32_t)a.nfeat - 1u;
     const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
-    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(a.table) + (chunk_part ? (Er - 4) * 4 : chunk * CB)
+    const char* row_base = chunk_ok ? reinterpret_cast<const char*>(a.table) + (chunk_part ? (Er - 4) * 4 : chunk * 16)
                                     : reinterpret_cast<const char*>(kZeroRow);
     constexpr int XQ = 4 * NTILE - NQ;
     constexpr int NZ = ((7 + 4 * XQ) * (E / 4) + 63) / 64;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         for (int n = 0; n < NI; ++n) {
             const int row = n * RPI + lane / CH;
             RowT r = rwC[n] * vC[n];
-            if constexpr (CB == 16) {
+            {
                 if (rem != 0) {                                         // kernel-uniform
                     const f32x4 t = rem == 1 ? f32x4{r[3], 0.f, 0.f, 0.f}
                                   : rem == 2 ? f32x4{r[2], r[3], 0.f, 0.f} : f32x4{r[1], r[2], r[3], 0.f};
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     }
 }
 
-template <int E, int NQ, int MODE, int SRC, int CB>
+template <int E, int NQ, int MODE, int SRC>
 static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     constexpr int NTILE = (NQ + 3) / 4, ROWS = NTILE * 16;
     constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 2 * 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
@@ -624,7 +624,7 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     const int64_t blocks = (a.B + 3) / 4;
     const int64_t resident = 256 * (int64_t)per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
-    auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC, CB>;
+    auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -633,14 +633,14 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     return ARMNET_OK;
 }
 
-template <int E, int NQ, int CB>
+template <int E, int NQ>
 static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
 #define ARMNET_BWD_MODE(SRC)                                                                         \
     switch (a.cfg.mode) {                                                                            \
-        case SOLVE_SOFTMAX: return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, SRC, CB>(a, st);             \
-        case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC, CB>(a, st);           \
-        case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC, CB>(a, st);           \
-        case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC, CB>(a, st);               \
+        case SOLVE_SOFTMAX: return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, SRC>(a, st);             \
+        case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);           \
+        case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);           \
+        case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);               \
         default: return ARMNET_ERR_UNSUPPORTED;                                                      \
     }
     if (a.id_type == ARMNET_ID_I64) { ARMNET_BWD_MODE(0) }
@@ -648,9 +648,8 @@ static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
 #undef ARMNET_BWD_MODE
 }
 
-int launch_bwd_mfma_e16_c16(const BwdArgs& a, int nq, hipStream_t st);
-int launch_bwd_mfma_e16_c8(const BwdArgs& a, int nq, hipStream_t st);
-int launch_bwd_mfma_e32_c16(const BwdArgs& a, int nq, hipStream_t st);
-int launch_bwd_mfma_e64_c16(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e16(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e32(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e64(const BwdArgs& a, int nq, hipStream_t st);
 
 }  // namespace armnet

@@ -3,9 +3,9 @@
 
 namespace armnet {
 
-// nemb 2 or 4..64 (any, odd too); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
+// nemb 4..64 (any, odd too: 16-byte staging chunks at the rows' natural 4-byte alignment); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
 bool fused_mfma_supports(int F, int E, int O) {
-    if (E < 2 || E > 64 || E == 3 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
+    if (E < 4 || E > 64 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
     const int nq = (((F + 3) / 4) + 1) & ~1;
     // LDS of one block (same formula as launch_one): 4 wave tiles + the lane-ready parameters of one slice
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
@@ -21,9 +21,6 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B * a.F >= ((int64_t)1 << 29)) return ARMNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into ids/vals
     if (!fused_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;            // quarter-steps per sample, rounded up to even
-    // 16-byte staging chunks for every nemb >= 4 (rows need only their natural 4-byte alignment: the partial last
-    // chunk is read from the row's last 16 bytes); the 8-byte family serves nemb = 2
-    const bool c16 = (a.E >= 4);
     // > 256 neurons: the lane-ready parameter copies no longer fit in LDS next to the tiles -> slices of 256
     // (each slice re-gathers the rows; the in-place clamp is idempotent)
     for (int o0 = 0; o0 < a.O; o0 += 256) {
@@ -36,9 +33,9 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
         s.bn_shift = a.bn_shift + o0;
         s.out = a.out + (size_t)o0 * a.E;
         int rc;
-        if (a.E <= 16) rc = c16 ? launch_mfma_e16_c16(s, nq, st) : launch_mfma_e16_c8(s, nq, st);
-        else if (a.E <= 32) rc = launch_mfma_e32_c16(s, nq, st);
-        else rc = launch_mfma_e64_c16(s, nq, st);
+        if (a.E <= 16) rc = launch_mfma_e16(s, nq, st);
+        else if (a.E <= 32) rc = launch_mfma_e32(s, nq, st);
+        else rc = launch_mfma_e64(s, nq, st);
         if (rc != ARMNET_OK) return rc;      // a refusal can only happen on the first slice (same shape after it)
     }
     return ARMNET_OK;

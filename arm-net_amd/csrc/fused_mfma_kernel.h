@@ -109,13 +109,12 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 
 // E = nemb padded to 16/32/64; NQ = quarter-steps per sample (even); SPW samples per wave-group;
 // SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows; WPS = waves/SIMD the register budget targets;
-// CB = bytes per staging lane (16; the 8-byte family serves nemb = 2)
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int CB>
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS>
 __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
     constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
     constexpr int ES = E + 4;                 // LDS row stride (floats)
-    constexpr int CF = CB / 4;                // floats per staging lane
+    constexpr int CF = 4;                     // floats per staging lane (16-byte chunks)
     constexpr int CH = E / CF;                // chunks per (padded) row
     constexpr int RPI = 64 / CH;              // rows per staging instruction
     constexpr int NI = NTILE * 16 / RPI;      // staging instructions per group
@@ -124,10 +123,9 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr bool FROM_ROWS = (SRC == 2);
     constexpr int TILE_FLOATS = NTILE * 16 * ES;
     constexpr int WAVE_FLOATS = TILE_FLOATS + 256;       // + reduction scratch (2 slots x 128 floats)
-    static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0 && NQ % 2 == 0 && SPW <= 2 &&
-                  (CB == 16 || CB == 8), "shape");
-    using RowT = typename std::conditional<CB == 16, f32x4, f32x2>::type;
-    using RowTU = typename std::conditional<CB == 16, f32x4u, f32x2u>::type;     // as read from global memory
+    static_assert(E % 16 == 0 && (NTILE * 16) % RPI == 0 && NQ % 2 == 0 && SPW <= 2, "shape");
+    using RowT = f32x4;
+    using RowTU = f32x4u;                     // as read from global memory
 
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -152,10 +150,10 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
-    // a chunk is full (inside the row), partial (CB = 16 only: the row ends inside it; it is loaded from the LAST 16
+    // a chunk is full (inside the row), partial (the row ends inside it; it is loaded from the LAST 16
     // bytes of the row instead and rotated into place) or padding (reads zeros)
-    const int rem = (CB == 16) ? (Er & 3) : 0;           // floats of the partial chunk (0: there is none)
-    const bool chunk_part = (CB == 16) && rem != 0 && chunk == (Er >> 2);
+    const int rem = Er & 3;                              // floats of the partial chunk (0: there is none)
+    const bool chunk_part = rem != 0 && chunk == (Er >> 2);
     const bool chunk_ok = (chunk + 1) * CF <= Er || chunk_part;
     uint32_t off4[NI];   // 4 * (s*F + f) of the row this lane stages in instruction n (0 for a pad row)
     bool pad[NI];        // pad row (field >= nfield, or a quarter-step past the group): zeroed after staging
@@ -191,7 +189,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     // lanes whose chunk lies in the zero padding of a row (nemb < E) read zeros: lane-constant base and stride
     const uint32_t row_bytes = chunk_ok ? (uint32_t)Er * 4u : 0u;
     const char* row_base = chunk_ok ? reinterpret_cast<const char*>(FROM_ROWS ? a.rows : a.table) +
-                                          (chunk_part ? (Er - 4) * 4 : chunk * CB)
+                                          (chunk_part ? (Er - 4) * 4 : chunk * 16)
                                     : reinterpret_cast<const char*>(kZeroRow);
     // pad rows are staged like any other (their lanes re-read element 0 of the group) and then overwritten with
     // zeros, so that a non-finite embedding of one sample cannot leak into its group neighbour through 0 * NaN.
@@ -337,7 +335,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             vcl[n] = v;
             changed |= (v != vraw) && !pad[n];
             RowT r = rows_cur[n] * v;
-            if constexpr (CB == 16) {
+            {
                 if (rem != 0) {                                         // kernel-uniform
                     // partial chunk: the lane holds the row's last 4 floats; its own are the last `rem` of them
                     const f32x4 t = rem == 1 ? f32x4{r[3], 0.f, 0.f, 0.f}
@@ -635,14 +633,14 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 
 // SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
 // nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
-template <int E, int NQ, int MODE, int SRC, int CB>
+template <int E, int NQ, int MODE, int SRC>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
     constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
     // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
     // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
     // generic-alpha Newton keeps two transcendental temporaries per pair alive)
     constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
-                        : (E >= 32 || MODE == SOLVE_NEWTON || CB == 8) ? 3      // measured: nemb=32 is faster at 3
+                        : (E >= 32 || MODE == SOLVE_NEWTON) ? 3      // measured: nemb=32 is faster at 3
                         : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
                         : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
@@ -663,7 +661,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
         if (want > blocks) want = blocks;
         if (want < 1) want = 1;
     }
-    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, CB>;
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -672,31 +670,30 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     return ARMNET_OK;
 }
 
-template <int E, int NQ, int SRC, int CB>
+template <int E, int NQ, int SRC>
 static int launch_mode(const FusedArgs& a, hipStream_t st) {
     switch (a.cfg.mode) {
-        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC, CB>(a, st);
-        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC, CB>(a, st);
-        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC, CB>(a, st);
-        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC, CB>(a, st);
+        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC>(a, st);
+        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);
+        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);
+        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);
         default: return ARMNET_ERR_UNSUPPORTED;
     }
 }
 
 // ids (int64 / int32) for every shape; the pre-gathered-rows source only where WITH_ROWS
-template <int E, int NQ, int CB, bool WITH_ROWS>
+template <int E, int NQ, bool WITH_ROWS>
 static int launch_src(const FusedArgs& a, hipStream_t st) {
     if (a.rows != nullptr) {
-        if constexpr (WITH_ROWS) return launch_mode<E, NQ, 2, CB>(a, st);
+        if constexpr (WITH_ROWS) return launch_mode<E, NQ, 2>(a, st);
         else return ARMNET_ERR_UNSUPPORTED;
     }
-    return a.id_type == ARMNET_ID_I64 ? launch_mode<E, NQ, 0, CB>(a, st) : launch_mode<E, NQ, 1, CB>(a, st);
+    return a.id_type == ARMNET_ID_I64 ? launch_mode<E, NQ, 0>(a, st) : launch_mode<E, NQ, 1>(a, st);
 }
 
 // one translation unit per family keeps the build parallel
-int launch_mfma_e16_c16(const FusedArgs& a, int nq, hipStream_t st);
-int launch_mfma_e16_c8(const FusedArgs& a, int nq, hipStream_t st);
-int launch_mfma_e32_c16(const FusedArgs& a, int nq, hipStream_t st);
-int launch_mfma_e64_c16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e32(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e64(const FusedArgs& a, int nq, hipStream_t st);
 
 }  // namespace armnet

@@ -77,7 +77,7 @@ def test_a_few_adam_steps_reduce_the_loss():
 
 # (nfield, nemb, neurons, alpha): every staging family and solver mode of the matrix-core backward, neuron counts that
 # need padding and more than one 64-neuron slice
-BWD_SWEEP = [(1, 2, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5), (9, 14, 33, 1.0), (13, 8, 16, 2.0),
+BWD_SWEEP = [(1, 4, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5), (9, 14, 33, 1.0), (13, 8, 16, 2.0),
              (17, 20, 5, 2.0), (22, 32, 32, 2.0), (22, 10, 64, 1.5), (25, 28, 70, 1.5), (31, 32, 64, 1.0),
              (39, 16, 32, 2.0), (39, 16, 32, 1.5), (39, 16, 32, 1.7), (39, 16, 32, 1.0), (39, 10, 128, 2.0),
              (43, 10, 96, 1.7), (47, 8, 19, 2.0), (48, 64, 24, 2.0), (39, 64, 32, 1.5), (30, 40, 20, 1.7), (6, 60, 7, 1.0),

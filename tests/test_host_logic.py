@@ -56,7 +56,7 @@ def test_kernel_selection_covers_the_reference_run_sh_shapes():
     assert k(39, 10, 128, 2.0, n_iter=10) == 0                    # too few iterations to have converged
     assert k(39, 10, 128, 2.0, flags=native.F_FAITHFUL_BISECT) == 0
     assert k(39, 10, 128, 2.0, flags=native.F_FORCE_GENERIC) == 0
-    assert k(39, 11, 128, 2.0) == 1 and k(39, 3, 128, 2.0) == 0 and k(39, 128, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
+    assert k(39, 11, 128, 2.0) == 1 and k(39, 3, 128, 2.0) == 0 and k(39, 2, 128, 2.0) == 0 and k(39, 128, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
     with pytest.raises(native.ArmnetNativeError):
         k(0, 16, 32, 2.0)
 
