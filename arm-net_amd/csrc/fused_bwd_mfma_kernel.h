@@ -212,16 +212,15 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             zN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
             dN[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (o < O) {
-                if (full_rows || 16 * eb + 4 * g + 4 <= Er) {
+                const int e0 = 16 * eb + 4 * g;
+                if (full_rows || e0 + 4 <= Er) {
                     zN[eb] = *reinterpret_cast<const f32x4u*>(a.z + zo + 16 * eb);
                     dN[eb] = *reinterpret_cast<const f32x4u*>(a.dz + zo + 16 * eb);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * eb + 4 * g + r < Er) {
-                            zN[eb][r] = a.z[zo + 16 * eb + r];
-                            dN[eb][r] = a.dz[zo + 16 * eb + r];
-                        }
+                } else if (e0 < Er) {
+                    // the row ends inside this lane's 4 floats: read the row's LAST 4 (in bounds) and keep the tail;
+                    // rotated into place when consumed (zd_rotate)
+                    zN[eb] = *reinterpret_cast<const f32x4u*>(a.z + zo - 4 * g + (Er - 4));
+                    dN[eb] = *reinterpret_cast<const f32x4u*>(a.dz + zo - 4 * g + (Er - 4));
                 }
             }
         }
@@ -306,6 +305,16 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                 const f32x4 cf = *reinterpret_cast<const f32x4*>(p_cf + 4 * (16 * nt + c));
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
+                    if (rem != 0) {                                     // kernel-uniform: partial last chunk of z / dz
+                        const bool part = (16 * eb + 4 * g < Er) && (16 * eb + 4 * g + 4 > Er);
+                        const f32x4 zz = zN[eb], dd = dN[eb];
+                        const f32x4 zt = rem == 1 ? f32x4{zz[3], 0.f, 0.f, 0.f}
+                                       : rem == 2 ? f32x4{zz[2], zz[3], 0.f, 0.f} : f32x4{zz[1], zz[2], zz[3], 0.f};
+                        const f32x4 dt = rem == 1 ? f32x4{dd[3], 0.f, 0.f, 0.f}
+                                       : rem == 2 ? f32x4{dd[2], dd[3], 0.f, 0.f} : f32x4{dd[1], dd[2], dd[3], 0.f};
+                        zN[eb] = part ? zt : zz;
+                        dN[eb] = part ? dt : dd;
+                    }
                     f32x4 dzv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dzv[r] = fmaf(cf[0], dN[eb][r], fmaf(cf[2], zN[eb][r], cf[1]));
