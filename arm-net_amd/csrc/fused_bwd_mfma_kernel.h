@@ -28,9 +28,12 @@ namespace armnet {
 // Passes (16 neurons each) per launch: the d_values / d_qfold accumulators of a launch's neuron slice stay in
 // registers over all samples of a wave (LDS float atomics from 4 waves on the same addresses cost more than the rest
 // of the kernel: measured 888 -> 368 us), so the slice is what the register file holds beside the dx tiles:
-// 4 passes for nemb <= 16, 2 for nemb <= 32, 1 for nemb = 64.  Wider blocks run as several launches, each of which
+// 4 passes for nemb <= 16, 2 above.  Wider blocks run as several launches, each of which
 // re-stages the rows and scatters its part of dx.
-constexpr int bwd_passes(int E) { return E >= 64 ? 1 : E > 16 ? 2 : 4; }
+#ifndef ARMNET_BWD_E64_PASSES
+#define ARMNET_BWD_E64_PASSES 2    // measured: 2 passes with ~128 B of scratch beat 1 pass without (1.42 vs 1.74 ms)
+#endif
+constexpr int bwd_passes(int E) { return E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : 4; }
 
 template <int E, int NQ, int MODE, int SRC>
 __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {

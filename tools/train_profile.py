@@ -11,7 +11,7 @@ from models.armnet_1h import ARMNetModel
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 alpha = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
-F, E, H, nfeat = 39, 16, 32, 1_000_000
+F, E, H, nfeat = 39, int(os.environ.get("NEMB", 16)), int(os.environ.get("NHID", 32)), 1_000_000
 torch.manual_seed(0)
 ens = len(sys.argv) > 3 and sys.argv[3] == "ens"
 m = ARMNetModel(F, nfeat, E, alpha, H, E, 2, 256, 0.0, ens, 2, 256).cuda().train()
