@@ -173,8 +173,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or bool(os.environ.get("ARMNET_BENCH_FORCE_DIST"))   # FORCE: exercise RCCL with 1 rank
+    # developer knobs for a 1-GPU box: ARMNET_BENCH_BACKEND=gloo ARMNET_BENCH_DEVICE=0 run the N > 1 flow with
+    # several ranks sharing one device (the exchanges of the row-sharded variant are then staged through the host)
+    backend = os.environ.get("ARMNET_BENCH_BACKEND", "nccl")
+    if "ARMNET_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["ARMNET_BENCH_DEVICE"])
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
