@@ -41,7 +41,7 @@ class ArmBlockParams:
 
 
 def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
-                      write_clamped_vals=True, check_ids=True, flags=0, rows=None):
+                      write_clamped_vals=True, check_ids=True, flags=0, rows=None, out=None):
     """Fused a2..a9.  Returns out [B, O, E] (post-BN).  ``vals`` is clamped in place
     when write_clamped_vals (the reference's side effect, armnet_1h.py:81).  With check_ids an
     out-of-range id raises IndexError like the reference's CPU path (costs one host sync)."""
@@ -51,7 +51,10 @@ def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alph
     B, F = vals.shape
     O, E = q_fold.shape
     values2d = values.detach().reshape(O, F)
-    out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, O, E) or not out.is_contiguous():
+        raise native.ArmnetNativeError(f"out must be a contiguous [{B}, {O}, {E}] tensor")
     fl = flags | (native.F_WRITE_CLAMPED_VALS if write_clamped_vals else 0)
     if rows is not None:
         native.fused_fwd_from_rows(B, F, E, O, alpha, n_iter, fl, rows, vals, q_fold, values2d, bn_scale,

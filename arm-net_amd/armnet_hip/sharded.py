@@ -60,6 +60,7 @@ class RowShardedTable:
 
     def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto"):
         self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
+        self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
         self.table_local = table_local
         self.nfeat = int(nfeat)
         self.group = group
@@ -79,7 +80,12 @@ class RowShardedTable:
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
         dedup = (8 * n >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
-        counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
+        if n == 0:                                     # an empty slice still takes part in the exchanges
+            counts = torch.zeros(R, device=flat.device, dtype=torch.int32)
+            send_local = torch.empty(0, device=flat.device, dtype=torch.int32)
+            perm = torch.empty(0, device=flat.device, dtype=torch.int32)
+        else:
+            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
         E = self.table_local.shape[1]
         if R == 1 and not dist.is_initialized():
             n_send = int(counts.sum().item()) if dedup else n
@@ -112,10 +118,37 @@ class RowShardedTable:
 
 
 def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
-                      write_clamped_vals=True, flags=0):
-    """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E]."""
+                      write_clamped_vals=True, flags=0, micro_batches=None):
+    """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E].
+
+    With micro_batches > 1 the batch is processed in slices whose lookups (routing, the two exchanges, the owner-side
+    gather) run on a side stream, so the exchange of slice m+1 overlaps the fused kernel of slice m.  Every rank must
+    use the same number of slices (the collectives pair up slice by slice).  Default: `shard.micro_batches` (1)."""
     from .block import arm_block_forward
-    rows, perm = shard.lookup(ids)
     B, F = vals.shape
-    return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
-                             n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags)
+    M = int(micro_batches if micro_batches is not None else getattr(shard, "micro_batches", 1))
+    if M <= 1 or not vals.is_cuda:
+        rows, perm = shard.lookup(ids)
+        return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
+                                 n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags)
+    O, E = q_fold.shape
+    out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+    compute = torch.cuda.current_stream()
+    side = getattr(shard, "_side_stream", None)
+    if side is None:
+        side = shard._side_stream = torch.cuda.Stream()
+    side.wait_stream(compute)                       # ids / vals were produced on the compute stream
+    step = (B + M - 1) // M
+    for m in range(M):
+        lo, hi = m * step, min(B, (m + 1) * step)   # every rank runs M slices, possibly an empty last one
+        with torch.cuda.stream(side):
+            rows, perm = shard.lookup(ids[lo:hi])
+            ready = side.record_event()
+        if hi > lo:
+            compute.wait_event(ready)
+            rows.record_stream(compute)
+            perm.record_stream(compute)
+            arm_block_forward(perm.view(hi - lo, F), vals[lo:hi], rows, q_fold, values, bn_scale, bn_shift, alpha,
+                              n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags,
+                              out=out[lo:hi])
+    return out

@@ -51,6 +51,8 @@ def parse():
                     help="replicate = every rank holds the table (no collective); rows = table row-sharded over "
                          "the ranks, RCCL all-to-all lookup (SURVEY §8e); both (default when N > 1) = value from "
                          "replicate plus a row_sharded object measured in the same run")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="row-sharded variant: slices per step whose exchanges overlap the previous slice's kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -85,6 +87,7 @@ def build_model(a, device, rank=0, world=1):
         gdev = torch.Generator(device=device).manual_seed(2025 + rank)
         shard = (torch.rand(n_local, a.nemb, device=device, generator=gdev) * 2 - 1) * bound
         m._shard = RowShardedTable(shard, a.nfeat, None)
+        m._shard.micro_batches = a.micro_batches
         m.nfeat = a.nfeat
     return m
 
@@ -227,6 +230,7 @@ def main():
             try:
                 torch.cuda.set_device(local)
                 model.shard_embedding()
+                model._shard.micro_batches = a.micro_batches
                 for _ in range(a.warmup):
                     step_block()
                 ms, _ = timed(step_block, a.steps, sync_all)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dedup, q):
+def _worker(rank, world, port, dedup, micro, q):
     for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,6 +37,7 @@ def _worker(rank, world, port, dedup, q):
             want = m.arm_block(ids.to(dev), vals.clone().to(dev))
             m.shard_embedding()
             m._shard.dedup = dedup
+            m._shard.micro_batches = micro
             assert m._shard.world == world and m._shard._via_host
             got = m.arm_block(ids.to(dev), vals.clone().to(dev))
         q.put((rank, bool(torch.equal(got, want)), float((got - want).abs().max())))
@@ -44,12 +45,14 @@ def _worker(rank, world, port, dedup, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dedup", [False, True])
-def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup):
+@pytest.mark.parametrize("dedup,micro", [(False, 1), (True, 1), (True, 3), (False, 500)])
+def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro):
+    """micro > 1: the lookups of slice m+1 run on a side stream beside the fused kernel of slice m; 500 slices for
+    333 / 340 samples also exercises empty slices (every rank still takes part in every exchange)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29621 + int(dedup)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, q)) for r in range(2)]
+    port = 29621 + 2 * int(dedup) + (micro > 1) + 4 * (micro > 100)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, micro, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
