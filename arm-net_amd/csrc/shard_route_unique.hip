@@ -55,7 +55,8 @@ __global__ void uniq_perm_kernel(int64_t n, const IdT* __restrict__ ids, int R, 
 
 static size_t scan_temp_bytes(int64_t P) {
     size_t bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (int)P);
+    // size query only (null temp storage): cannot fail for a valid item count
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (int)P);
     return (bytes + 255) & ~(size_t)255;
 }
 
