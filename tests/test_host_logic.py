@@ -34,6 +34,21 @@ def test_abi_argument_validation_without_device():
     assert lib.armnet_clamp_vals_f32(None, ctypes.c_int64(-1), None) == native.ERR_BAD_ARG
     assert lib.armnet_entmax_f32(ctypes.c_int64(4), 0, ctypes.c_float(1.5), 50, 1, 0, None, None, None) == native.ERR_BAD_ARG
     assert lib.armnet_fold_params_f32(0, 2, 4, 4, 4, *([None] * 9), ctypes.c_float(1e-5), None) == native.ERR_BAD_ARG
+    i64 = ctypes.c_int64
+    assert lib.armnet_bn_stats_f32(i64(8), 0, 1, None, None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_bn_stats_f32(i64(8), 4, 1, None, None, None) == native.ERR_BAD_ARG              # null x
+    assert lib.armnet_bn_finalize_f32(4, i64(0), *([None] * 2), 1, None, None, ctypes.c_float(1e-5),
+                                      ctypes.c_float(0.1), *([None] * 7)) == native.ERR_BAD_ARG
+    assert lib.armnet_bn_apply_f32(i64(8), 4, 1, None, None, None, 0, None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_bn_bwd_reduce_f32(i64(8), 4, 1, *([None] * 8)) == native.ERR_BAD_ARG
+    assert lib.armnet_bn_bwd_coef_f32(4, i64(8), *([None] * 10)) == native.ERR_BAD_ARG
+    assert lib.armnet_bn_bwd_apply_f32(i64(8), 4, 1, *([None] * 9)) == native.ERR_BAD_ARG
+    assert lib.armnet_scatter_add_f32(i64(8), 4, None, 0, None, None, i64(10), None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_fused_bwd_bn_f32(i64(8), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0,
+                                       *([None] * 2), i64(100), *([None] * 11)) == native.ERR_BAD_ARG
+    # an empty batch is a no-op even with null buffers
+    assert lib.armnet_fused_fwd_f32(i64(0), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0, None, None,
+                                    i64(100), *([None] * 7)) == native.OK
     assert b"out of range" in lib.armnet_strerror(native.ERR_ID_RANGE)
     with pytest.raises(IndexError):
         native.check(native.ERR_ID_RANGE)
