@@ -13,6 +13,18 @@ void set_hip_error(hipError_t e, const char* where) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }
 
+int device_cu_count() {
+    static thread_local int cached_dev = -1, cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        cached_cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cached_dev = dev;
+    }
+    return cached_cus;
+}
+
 }  // namespace armnet
 
 using namespace armnet;
@@ -24,7 +36,7 @@ int armnet_abi_version(void) { return ARMNET_ABI_VERSION; }
 const char* armnet_strerror(int status) {
     switch (status) {
         case ARMNET_OK: return "ok";
-        case ARMNET_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or misaligned buffer)";
+        case ARMNET_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
         case ARMNET_ERR_UNSUPPORTED: return "unsupported shape (per-block LDS tile would exceed 64 KiB, or nfeat >= 2^31)";
         case ARMNET_ERR_ID_RANGE: return "index out of range in self";
         case ARMNET_ERR_HIP: return "HIP runtime error (see armnet_last_hip_error)";

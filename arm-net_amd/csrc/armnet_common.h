@@ -54,6 +54,9 @@ constexpr int kNewtonMaxIter = 40;
 #endif
 constexpr float kNewtonTol = ARMNET_NEWTON_TOL;   // stop once sum(p) - 1 <= tol (a few fp32 ulps of 1)
 
+// compute units of the current device (256 on MI355X), cached per device; 256 if the query fails
+int device_cu_count();
+
 // thread-local record of the last HIP failure (armnet_last_hip_error)
 void set_hip_error(hipError_t e, const char* where);
 

@@ -630,11 +630,13 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
                   (size_t)OP * (E + 4) + (size_t)OP * 4) * sizeof(float);
     if ((size_t)OP * (4 * NQ + E) > (size_t)4 * WAVE_FLOATS) return ARMNET_ERR_UNSUPPORTED;    // the aliased accumulators
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
+#ifdef ARMNET_DEV_FLAGS
     if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
+#endif
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > 2) per_cu = 2;
     const int64_t blocks = (a.B + 3) / 4;
-    const int64_t resident = 256 * (int64_t)per_cu;
+    const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
     auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC>;
     if (lds > 64 * 1024)

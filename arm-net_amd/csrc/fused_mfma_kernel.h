@@ -653,14 +653,16 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > WPS) per_cu = WPS;
     if (per_cu < 1) per_cu = 1;
-    const int64_t resident = 256 * (int64_t)per_cu;              // blocks the chip holds at once
+    const int64_t resident = (int64_t)device_cu_count() * per_cu;   // blocks the chip holds at once
     // persistent grid-stride waves: the software pipeline's prologue is paid once per wave
     int64_t want = blocks < resident ? blocks : resident;
+#ifdef ARMNET_DEV_FLAGS
     if (const char* gm = getenv("ARMNET_GRID_MULT")) {          // developer knob: oversubscribe the grid
         want = (int64_t)(resident * atof(gm));
         if (want > blocks) want = blocks;
         if (want < 1) want = 1;
     }
+#endif
     auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -32,7 +32,7 @@ extern "C" {
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
-    ARMNET_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, misaligned buffer */
+    ARMNET_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, inconsistent arguments */
     ARMNET_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover (see armnet_strerror) */
     ARMNET_ERR_ID_RANGE = -3,     /* reserved for host-side checked wrappers (IndexError) */
     ARMNET_ERR_HIP = -4           /* a HIP runtime call failed: see armnet_last_hip_error() */
