@@ -431,3 +431,14 @@ def test_misaligned_buffers_and_empty_batch():
     e_out = torch.empty(0, O, E, device=DEV)
     native.fused_fwd(0, F, E, O, alpha, 50, 0, e_ids, e_vals, table, qf, values, sc, sh, e_out)
     torch.cuda.synchronize()
+
+
+def test_roc_auc_on_device_matches_sklearn():
+    """the same check as the CPU suite's, with the tensors on the GPU (sort / cumsum / bincount on the device)"""
+    from sklearn.metrics import roc_auc_score
+    from armnet_hip.metrics import roc_auc_device
+    g = torch.Generator().manual_seed(12)
+    y = (torch.rand(200000, generator=g) > 0.7).float()
+    p = torch.round((torch.randn(200000, generator=g) + y) * 64) / 64
+    got = roc_auc_device(p.to(DEV), y.to(DEV))
+    assert got.is_cuda and abs(float(got) - roc_auc_score(y.numpy(), p.numpy())) <= 1e-10

@@ -151,3 +151,23 @@ print("OK")
 ''' % os.path.join(ROOT, "arm-net_amd")
     out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_roc_auc_matches_sklearn_including_ties():
+    """armnet_hip.metrics.roc_auc_compute_fn (sort + prefix sums on the tensors' device) against
+    sklearn.metrics.roc_auc_score, the reference's helper (utils/utils.py:85-106)"""
+    import numpy as np
+    import torch
+    from sklearn.metrics import roc_auc_score
+    from armnet_hip.metrics import roc_auc_compute_fn, roc_auc_device
+    g = torch.Generator().manual_seed(11)
+    for n, quant in ((1000, None), (5000, 16), (37, 3), (2, None)):
+        y = (torch.rand(n, generator=g) > 0.6).float()
+        y[0], y[1] = 0.0, 1.0                                   # both classes present
+        p = torch.randn(n, generator=g) + y * 0.7
+        if quant:
+            p = torch.round(p * quant) / quant                  # many tied scores
+        want = roc_auc_score(y.numpy(), p.numpy())
+        assert abs(roc_auc_compute_fn(p, y) - want) <= 1e-12
+        assert abs(float(roc_auc_device(p.requires_grad_(True), y)) - want) <= 1e-12
+    assert roc_auc_compute_fn(torch.randn(5), torch.ones(5)) == 0.      # one class only, like the reference helper
