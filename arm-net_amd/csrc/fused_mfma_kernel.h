@@ -1,5 +1,5 @@
 // fused_mfma_kernel.h — the fused ARM block on the CDNA4 matrix cores (gfx950), fp32 end to end.
-// Template + launcher; instantiated per (padded embedding width, chunk size) family in fused_mfma_*.hip.
+// Template + launcher; instantiated per padded embedding width (16 / 32 / 64) in fused_mfma_e*.hip.
 //
 // Measured facts this kernel is built around (tools/ubench/valu_rate.hip, profiles/):
 //   * v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and its cycles ADD to the VALU cycles of
@@ -26,10 +26,10 @@
 //             alpha = 2: Michelot (= Newton from the left, finite), alpha = 1.5 / generic: Newton.
 //   MFMA #2   Z^T[e, o] = sum_f X[f, e] * W[o, f]:  the C layout of MFMA #1 IS the B-operand layout
 //             of MFMA #2 (k = lane group g <-> field 4j+g): the weights never move.
-//   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte
-//             store per lane when nemb is a multiple of 16 (element stores otherwise).
+//   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte store per lane
+//             and 16 embedding dims (4-byte aligned; the partial last chunk of a row as 8 bytes or elements).
 //
-// Shapes: nemb 2 or 4..64, nfield <= 48, nhead*nhid <= 256 per launch (neurons padded to 16 per pass).
+// Shapes: nemb 4..64, nfield <= 48, nhead*nhid <= 256 per launch (neurons padded to 16 per pass).
 #pragma once
 #include <stdlib.h>
 
