@@ -288,6 +288,7 @@ def main():
     entmax_cases()
     entmax_grad_cases()
     run_sh_cases()
+    run_sh_grad_cases()
 
 
 def run_sh_cases():
@@ -312,6 +313,19 @@ def run_sh_cases():
                7, 98, "stress")
     model_case("g9_diabetes_mh8_h64_e10_a1.5", "mh", base(43, 369, 10, 1.5, 64, nhead=8, mlp_nlayer=1, mlp_nhid=8),
                5, 99, "stress")
+
+
+def run_sh_grad_cases():
+    """H2 - gradients of one training step at the block shapes of the reference's run.sh (nemb = 10: rows whose last
+    16-byte chunk is partial; 128-512 neurons: several backward launches)."""
+    grad_case("h2_grad_criteo_1h_h128_e10_a2.0_train", "1h", base(39, 200, 10, 2.0, 128, mlp_nhid=16), 16, 101, True)
+    grad_case("h2_grad_avazu_1h_h128_e10_a1.5_train", "1h", base(22, 200, 10, 1.5, 128, mlp_nlayer=3, mlp_nhid=16), 16, 102, True)
+    grad_case("h2_grad_frappe_mh8_h32_e10_a2.0_train", "mh", base(10, 200, 10, 2.0, 32, nhead=8, mlp_nhid=16), 16, 103, True)
+    grad_case("h2_grad_diabetes_mh32_h1_e10_a1.7_train", "mh", base(43, 369, 10, 1.7, 1, nhead=32, mlp_nlayer=1, mlp_nhid=16),
+              16, 104, True)
+    grad_case("h2_grad_movielens_1h_h128_e10_a2.0_evalbn", "1h", base(3, 200, 10, 2.0, 128, mlp_nhid=16), 16, 105, False)
+    grad_case("h2_grad_frappe_mh4_h4_e10_a1.5_ens_train", "mh",
+              base(10, 200, 10, 1.5, 4, nhead=4, ensemble=True, mlp_nhid=16, deep_nhid=16), 16, 106, True)
 
 
 def entmax_grad_cases():
@@ -340,6 +354,8 @@ def entmax_grad_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
         entmax_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":
+        run_sh_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others
         run_sh_cases()
     else:
