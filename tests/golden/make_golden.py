@@ -288,6 +288,7 @@ def main():
     entmax_cases()
     entmax_grad_cases()
     run_sh_cases()
+    more_cases()
     run_sh_grad_cases()
 
 
@@ -313,6 +314,17 @@ def run_sh_cases():
                7, 98, "stress")
     model_case("g9_diabetes_mh8_h64_e10_a1.5", "mh", base(43, 369, 10, 1.5, 64, nhead=8, mlp_nlayer=1, mlp_nhid=8),
                5, 99, "stress")
+
+
+def more_cases():
+    """G9b - alpha = 2.5 as run.sh:11,37 use it (MovieLens, ensemble); odd nemb (rows only 4-byte aligned)."""
+    model_case("g9_movielens_1h_h128_e10_a2.5_ens", "1h",
+               base(3, 300, 10, 2.5, 128, ensemble=True, mlp_nhid=16, deep_nhid=16), 11, 111, "stress")
+    model_case("g9_movielens_mh1_h8_e10_a2.5_ens", "mh",
+               base(3, 300, 10, 2.5, 8, nhead=1, ensemble=True, mlp_nhid=16, deep_nhid=16), 11, 112, "stress")
+    model_case("g7_odd_1h_f39_e7_h32_a2.0", "1h", base(39, 300, 7, 2.0, 32, mlp_nhid=16), 9, 113, "stress")
+    model_case("g7_odd_mh2_f22_e11_h20_a1.5", "mh", base(22, 300, 11, 1.5, 20, nhead=2, mlp_nhid=16), 9, 114, "stress")
+    model_case("g7_odd_1h_f10_e33_h16_a1.7", "1h", base(10, 300, 33, 1.7, 16, mlp_nhid=16), 9, 115, "stress")
 
 
 def run_sh_grad_cases():
@@ -356,6 +368,8 @@ if __name__ == "__main__":
         entmax_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":
         run_sh_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--more-only":
+        more_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others
         run_sh_cases()
     else:
