@@ -50,8 +50,14 @@ int launch_fold_params(int variant, int K, int H, int E, int D, const float* bw,
 
 // ---------------------------------------------------------------------------------------------
 // Embedding.forward alone (layers.py:20-21): out[r,:] = table[ids[r],:] * vals[r].
-// One lane per 16-byte chunk when E % 4 == 0 (adjacent lanes share a row -> one 64..256 B segment
-// per row), scalar lanes otherwise.
+// One lane per 16-byte chunk when E % 4 == 0, per 8-byte chunk when E is even (adjacent lanes share a row -> one
+// 4E-byte segment per row), scalar lanes otherwise.  The vector accesses need only 4-byte alignment (gfx950 runs in
+// unaligned access mode: still one dwordx4 / dwordx2 per lane).
+typedef float gs_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+typedef gs_f32x4 gs_f32x4u __attribute__((aligned(4)));
+typedef gs_f32x2 gs_f32x2u __attribute__((aligned(4)));
+
 template <typename IdT, int VEC>
 __global__ void gather_scale_kernel(int64_t n_rows, int E, const IdT* __restrict__ ids,
                                     const float* __restrict__ vals, const float* __restrict__ table,
@@ -69,9 +75,9 @@ __global__ void gather_scale_kernel(int64_t n_rows, int E, const IdT* __restrict
         const float* src = table + (size_t)id * E + c * VEC;
         float* dst = out + r * E + c * VEC;
         if constexpr (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(src);
-            t.x *= v; t.y *= v; t.z *= v; t.w *= v;
-            *reinterpret_cast<float4*>(dst) = t;
+            *reinterpret_cast<gs_f32x4u*>(dst) = *reinterpret_cast<const gs_f32x4u*>(src) * v;
+        } else if constexpr (VEC == 2) {
+            *reinterpret_cast<gs_f32x2u*>(dst) = *reinterpret_cast<const gs_f32x2u*>(src) * v;
         } else {
             dst[0] = src[0] * v;
         }
@@ -81,16 +87,16 @@ __global__ void gather_scale_kernel(int64_t n_rows, int E, const IdT* __restrict
 int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
                         const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s) {
     if (n_rows == 0) return ARMNET_OK;
-    const bool vec = (E % 4 == 0) && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0);
-    const int64_t total = n_rows * (vec ? E / 4 : E);
+    const int vec = (E % 4 == 0) ? 4 : (E % 2 == 0) ? 2 : 1;
+    const int64_t total = n_rows * (E / vec);
     const int block = 256;
     int64_t grid = (total + block - 1) / block;
     if (grid > 256 * 16) grid = 256 * 16;
 #define GS(IdT, V)                                                                                          \
     gather_scale_kernel<IdT, V><<<(int)grid, block, 0, s>>>(n_rows, E, (const IdT*)ids, vals, table, nfeat, \
                                                             out, id_status)
-    if (id_type == ARMNET_ID_I64) { if (vec) GS(int64_t, 4); else GS(int64_t, 1); }
-    else { if (vec) GS(int32_t, 4); else GS(int32_t, 1); }
+    if (id_type == ARMNET_ID_I64) { if (vec == 4) GS(int64_t, 4); else if (vec == 2) GS(int64_t, 2); else GS(int64_t, 1); }
+    else { if (vec == 4) GS(int32_t, 4); else if (vec == 2) GS(int32_t, 2); else GS(int32_t, 1); }
 #undef GS
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
