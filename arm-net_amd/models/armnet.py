@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from armnet_hip import native
+from utils.entmax import EntmaxBisect
 from armnet_hip.modules import ArmNetBase, SparseGateBase
 
 
@@ -18,6 +19,8 @@ class SparseAttLayer(SparseGateBase):
     def __init__(self, nhead, nfield, nemb, d_k, nhid, alpha=1.5):
         super().__init__()
         self.alpha = float(alpha)
+        # the reference keeps its normaliser as a sub-module of this name (no parameters: no state_dict keys)
+        self.sparsemax = nn.Softmax(dim=-1) if alpha == 1. else EntmaxBisect(alpha, dim=-1)
         self.scale = d_k ** -0.5
         self.bilinear_w = nn.Parameter(torch.zeros(nhead, nemb, d_k))
         self.query = nn.Parameter(torch.zeros(nhead, nhid, d_k))

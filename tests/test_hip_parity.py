@@ -442,3 +442,29 @@ def test_roc_auc_on_device_matches_sklearn():
     p = torch.round((torch.randn(200000, generator=g) + y) * 64) / 64
     got = roc_auc_device(p.to(DEV), y.to(DEV))
     assert got.is_cuda and abs(float(got) - roc_auc_score(y.numpy(), p.numpy())) <= 1e-10
+
+
+def test_integration_md_binding_stub_runs_as_written():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would add: execute that very
+    code (library path patched to the in-tree build) against a module with the reference's attribute names and
+    compare with the product path."""
+    import os
+    import re
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if "models/_armnet_hip.py" in b)
+    lib = os.path.join(root, "arm-net_amd", "lib", "libarmnet_hip.so")
+    stub = re.sub(r'ctypes\.CDLL\("[^"]*"\)', f'ctypes.CDLL("{lib}")', stub)
+    mod = types.ModuleType("_armnet_hip_stub")
+    exec(compile(stub, "INTEGRATION.md", "exec"), mod.__dict__)
+    meta, sd, ids, vals, ref = load("g2_criteo_1h_a2.0_stress")
+    m = build_model(meta, sd, DEV)
+    x = {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+    with torch.no_grad():
+        mod.fold(m)
+        got = mod.arm_block(m, x)
+        torch.cuda.synchronize()
+    assert _rel_err(got.cpu().numpy().reshape(ref["x_arm"].shape), ref["x_arm"]) <= TOL
+    np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])
