@@ -169,12 +169,12 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 
     // per-wave accumulators over all its samples: d_values in the C layout, d_qfold^T as MFMA #4's accumulator
     constexpr int NTS = bwd_passes(E);
-    float dvacc[NTS][NQ];
+    f32x2 dvacc[NTS][NP];                     // pairs (2jp, 2jp+1) like the gate registers
     f32x4 dqacc[NTS][EB];
 #pragma unroll
     for (int n = 0; n < NTS; ++n) {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) dvacc[n][j] = 0.f;
+        for (int jp = 0; jp < NP; ++jp) dvacc[n][jp] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) dqacc[n][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -485,30 +485,43 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 #pragma unroll
             for (int eb = 0; eb < EB; ++eb) *reinterpret_cast<f32x4*>(dsl + c * ES + 16 * eb + 4 * g) = ds4[eb];
 
-            // ---- d_values, dp, entmax / softmax Jacobian-vector product -------------------------------------
-            float s1 = 0.f, s2 = 0.f;
+            // ---- d_values, dp, entmax / softmax Jacobian-vector product: two elements per instruction -----------------
+#define DP_GET(jp) (f32x2{DG(2 * (jp)), DG(2 * (jp) + 1)})
+#define DP_SET(jp, v)            \
+    do {                         \
+        const f32x2 _v = (v);    \
+        DG(2 * (jp)) = _v[0];    \
+        DG(2 * (jp) + 1) = _v[1]; \
+    } while (0)
+            auto gppr = [&](f32x2 p2) -> f32x2 {                       // p^(2 - alpha) on the support, 0 off it
+                if constexpr (MODE == SOLVE_MICHELOT) {
+                    return pk_mul_clamp01(p2, f32x2{0x1p120f, 0x1p120f});
+                } else if constexpr (MODE == SOLVE_NEWTON15) {
+                    return f32x2{__builtin_sqrtf(p2[0]), __builtin_sqrtf(p2[1])};
+                } else {                                               // log2(0) = -inf -> exp2(-inf) = 0 (alpha < 2)
+                    return f32x2{__builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[0])),
+                                 __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[1]))};
+                }
+            };
+            f32x2 s12 = {0.f, 0.f}, s22 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const float p = XG(j), dW = DG(j);
-                const float v = VV(j >> 1)[j & 1];
-                dvacc[nt][j] = fmaf(p, dW, dvacc[nt][j]);
-                const float dp = v * dW;
+            for (int jp = 0; jp < NP; ++jp) {
+                const f32x2 p2 = XP_GET(jp), dW2 = DP_GET(jp), v2 = VV(jp);
+                dvacc[nt][jp] = __builtin_elementwise_fma(p2, dW2, dvacc[nt][jp]);
+                const f32x2 dp2 = v2 * dW2;
                 if constexpr (MODE == SOLVE_SOFTMAX) {
-                    DG(j) = dp;
-                    s1 = fmaf(p, dp, s1);
+                    DP_SET(jp, dp2);
+                    s12 = __builtin_elementwise_fma(p2, dp2, s12);
                 } else {
-                    float gp;
-                    if constexpr (MODE == SOLVE_MICHELOT) gp = p > 0.f ? 1.0f : 0.f;
-                    else if constexpr (MODE == SOLVE_NEWTON15) gp = __builtin_sqrtf(p);
-                    else gp = p > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p)) : 0.f;
-                    const float dxp = dp * gp;
-                    DG(j) = dxp;
-                    s1 += dxp;
-                    s2 += gp;
+                    const f32x2 gp2 = gppr(p2);
+                    const f32x2 dxp2 = dp2 * gp2;
+                    DP_SET(jp, dxp2);
+                    s12 += dxp2;
+                    s22 += gp2;
                 }
             }
             wave_lds_fence();
-            red_write(red, 0, lane, s1, s2);
+            red_write(red, 0, lane, s12[0] + s12[1], s22[0] + s22[1]);
             wave_lds_fence();
             float qv;
             {
@@ -516,20 +529,16 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                 const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);
                 qv = (MODE == SOLVE_SOFTMAX) ? sd[0] : sd[0] / sd[1];
             }
+            const f32x2 nq2 = {-qv, -qv};
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const float p = XG(j);
-                if constexpr (MODE == SOLVE_SOFTMAX) {
-                    DG(j) = p * (DG(j) - qv);
-                } else {
-                    float gp;
-                    if constexpr (MODE == SOLVE_MICHELOT) gp = p > 0.f ? 1.0f : 0.f;
-                    else if constexpr (MODE == SOLVE_NEWTON15) gp = __builtin_sqrtf(p);
-                    else gp = p > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p)) : 0.f;
-                    DG(j) = fmaf(-qv, gp, DG(j));
-                }
-                XG(j) = p * VV(j >> 1)[j & 1];                           // w = p * values
+            for (int jp = 0; jp < NP; ++jp) {
+                const f32x2 p2 = XP_GET(jp);
+                if constexpr (MODE == SOLVE_SOFTMAX) DP_SET(jp, p2 * (DP_GET(jp) + nq2));
+                else DP_SET(jp, __builtin_elementwise_fma(nq2, gppr(p2), DP_GET(jp)));
+                XP_SET(jp, p2 * VV(jp));                                 // w = p * values
             }
+#undef DP_GET
+#undef DP_SET
             // ---- w and dg transposed ([o][tile row]) for the contraction over neurons ------------------------
 #pragma unroll
             for (int t = 0; t < NTILE; ++t) {
@@ -602,7 +611,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
         if (nt >= NT) break;
         float* dv_row = acc_dv + (16 * nt + c) * FP + g;
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) atomicAdd(dv_row + 4 * j, dvacc[nt][j]);        // pad slots receive zeros
+        for (int j = 0; j < NQ; ++j) atomicAdd(dv_row + 4 * j, dvacc[nt][j >> 1][j & 1]);   // pad slots receive zeros
         float* dq_row = acc_dq + (16 * nt + c) * E + 4 * g;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb)
