@@ -30,13 +30,19 @@ namespace armnet {
 // of the kernel: measured 888 -> 368 us), so the slice is what the register file holds beside the dx tiles:
 // 4 passes for nemb <= 16, 2 above.  Wider blocks run as several launches, each of which
 // re-stages the rows and scatters its part of dx.
+#ifndef ARMNET_BWD_BLOCKS_PER_CU
+#define ARMNET_BWD_BLOCKS_PER_CU 2      // = waves per SIMD the register allocator targets
+#endif
+#ifndef ARMNET_BWD_E16_PASSES
+#define ARMNET_BWD_E16_PASSES 4
+#endif
 #ifndef ARMNET_BWD_E64_PASSES
 #define ARMNET_BWD_E64_PASSES 2    // measured: 2 passes with ~128 B of scratch beat 1 pass without (1.42 vs 1.74 ms)
 #endif
-constexpr int bwd_passes(int E) { return E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : 4; }
+constexpr int bwd_passes(int E) { return E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : ARMNET_BWD_E16_PASSES; }
 
 template <int E, int NQ, int MODE, int SRC>
-__global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_kernel(BwdArgs a) {
     constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
     constexpr int ROWS = NTILE * 16;
     constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
@@ -45,7 +51,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     constexpr int RS = ROWS + 4;              // row stride of the transposing buffers
     constexpr int FP = 4 * NQ;                // nfield padded
     constexpr int XT = ROWS * ES, RED = 128, TW = 16 * RS, DSL = 16 * ES, IDV = 2 * ROWS;
-    constexpr int WAVE_FLOATS = XT + RED + 2 * TW + DSL + IDV;
+    constexpr int WAVE_FLOATS = XT + RED + TW + DSL + IDV;
     static_assert(E % 16 == 0 && ROWS % RPI == 0 && NQ % 2 == 0, "shape");
     using RowT = f32x4;
     using RowTU = f32x4u;                     // as read from global memory
@@ -59,9 +65,8 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
     const int NT = (O + 15) / 16, OP = NT * 16;
     float* xt = lds_all + wave * WAVE_FLOATS;
     float* red = xt + XT;
-    float* tw = red + RED;                    // [16 o][RS]  w = p * values, transposed
-    float* tg = tw + TW;                      // [16 o][RS]  dg, transposed
-    float* dsl = tg + TW;                     // [16 o][ES]  ds = dz * z of this pass
+    float* tw = red + RED;                    // [16 o][RS]  transposing buffer: w = p * values, then dg
+    float* dsl = tw + TW;                     // [16 o][ES]  ds = dz * z of this pass
     uint32_t* idl = reinterpret_cast<uint32_t*>(dsl + DSL);   // [ROWS] table row of each tile row (~0u: pad row)
     float* vll = dsl + DSL + ROWS;            // [ROWS] value of each tile row
     // block-shared
@@ -539,12 +544,9 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
             }
 #undef DP_GET
 #undef DP_SET
-            // ---- w and dg transposed ([o][tile row]) for the contraction over neurons ------------------------
+            // ---- w transposed ([o][tile row]) for the contraction over neurons (dg follows through the same buffer) ----
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) {
-                *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c1[t];
-                *reinterpret_cast<f32x4*>(tg + c * RS + 16 * t + 4 * g) = c3[t];
-            }
+            for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c1[t];
             // ---- MFMA #4: dq_fold^T[e, o] += sum_f X[f, e] dg[o, f], accumulated over the wave's samples ------
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
@@ -554,26 +556,38 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
                     const float a2 = xt[row * ES + 16 * eb + c];
                     dqacc[nt][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, DG(j), dqacc[nt][eb], 0, 0, 0);
                 }
-            // ---- MFMA #5: dx[f, e] += sum_o w[o, f] ds[o, e] + dg[o, f] q_fold[o, e] ------------------------------
+            // ---- MFMA #5: dx[f, e] += sum_o w[o, f] ds[o, e] + dg[o, f] q_fold[o, e]: two halves through one buffer ------
             wave_lds_fence();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int ol = 4 * kk + g;                               // k index of this lane: neuron within the pass
-                float b1[EB], b2[EB];
+                float b1[EB];
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb) {
-                    b1[eb] = dsl[ol * ES + 16 * eb + c];
-                    b2[eb] = qfl[(16 * nt + ol) * ES + 16 * eb + c];
-                }
+                for (int eb = 0; eb < EB; ++eb) b1[eb] = dsl[ol * ES + 16 * eb + c];
 #pragma unroll
                 for (int t = 0; t < NTILE; ++t) {
                     const float a1 = tw[ol * RS + 16 * t + c];
-                    const float a2 = tg[ol * RS + 16 * t + c];
 #pragma unroll
-                    for (int eb = 0; eb < EB; ++eb) {
+                    for (int eb = 0; eb < EB; ++eb)
                         cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdx[t][eb], 0, 0, 0);
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c3[t];
+            wave_lds_fence();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ol = 4 * kk + g;
+                float b2[EB];
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) b2[eb] = qfl[(16 * nt + ol) * ES + 16 * eb + c];
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t) {
+                    const float a2 = tw[ol * RS + 16 * t + c];
+#pragma unroll
+                    for (int eb = 0; eb < EB; ++eb)
                         cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2[eb], cdx[t][eb], 0, 0, 0);
-                    }
                 }
             }
             wave_lds_fence();
@@ -633,7 +647,7 @@ __global__ void __launch_bounds__(256, 2) fused_bwd_mfma_kernel(BwdArgs a) {
 template <int E, int NQ, int MODE, int SRC>
 static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     constexpr int NTILE = (NQ + 3) / 4, ROWS = NTILE * 16;
-    constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 2 * 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
+    constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
     const int NT = (a.O + 15) / 16, OP = NT * 16;
     size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
                   (size_t)OP * (E + 4) + (size_t)OP * 4) * sizeof(float);
@@ -643,7 +657,7 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
 #endif
     int per_cu = (int)(160 * 1024 / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > ARMNET_BWD_BLOCKS_PER_CU) per_cu = ARMNET_BWD_BLOCKS_PER_CU;
     const int64_t blocks = (a.B + 3) / 4;
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
