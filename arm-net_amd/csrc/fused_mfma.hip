@@ -4,16 +4,31 @@
 namespace armnet {
 
 // nemb 4..64 (any, odd too: 16-byte staging chunks at the rows' natural 4-byte alignment); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
-bool fused_mfma_supports(int F, int E, int O) {
-    if (E < 4 || E > 64 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
+// LDS of one block for a slice of `o_slice` neurons (same formula as launch_one): 4 wave tiles + the lane-ready
+// parameters of the slice
+static size_t mfma_lds_bytes(int F, int E, int o_slice) {
     const int nq = (((F + 3) / 4) + 1) & ~1;
-    // LDS of one block (same formula as launch_one): 4 wave tiles + the lane-ready parameters of one slice
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
     const int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
-    const int ntile = (spw * nq + 3) / 4, nt = ((O < 256 ? O : 256) + 15) / 16;
-    const size_t lds = ((size_t)4 * (ntile * 16 * (ep + 4) + 256) + (size_t)nt * (ep / 16) * 256 +
-                        (size_t)nt * (nq / 2) * 128 + (size_t)nt * 32) * sizeof(float);
-    return lds <= 160 * 1024;
+    const int ntile = (spw * nq + 3) / 4, nt = (o_slice + 15) / 16;
+    return ((size_t)4 * (ntile * 16 * (ep + 4) + 256) + (size_t)nt * (ep / 16) * 256 + (size_t)nt * (nq / 2) * 128 +
+            (size_t)nt * 32) * sizeof(float);
+}
+
+// neurons per launch: as many as possible (each slice re-gathers the rows) while two blocks still fit a CU's LDS —
+// at 256 neurons the parameter copies of a 39-field block leave room for one block (1 wave/SIMD): measured 853 us
+// against 2 x 373 us for two launches of 128
+static int mfma_slice(int F, int E, int O) {
+    int slice = 256;
+    while (slice > 64 && slice / 2 >= 16 && (O > slice / 2) && mfma_lds_bytes(F, E, slice < O ? slice : O) > 80 * 1024)
+        slice /= 2;
+    return slice;
+}
+
+bool fused_mfma_supports(int F, int E, int O) {
+    if (E < 4 || E > 64 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
+    const int slice = mfma_slice(F, E, O);
+    return mfma_lds_bytes(F, E, O < slice ? O : slice) <= 160 * 1024;
 }
 
 int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
@@ -21,11 +36,12 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B * a.F >= ((int64_t)1 << 29)) return ARMNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into ids/vals
     if (!fused_mfma_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;            // quarter-steps per sample, rounded up to even
-    // > 256 neurons: the lane-ready parameter copies no longer fit in LDS next to the tiles -> slices of 256
-    // (each slice re-gathers the rows; the in-place clamp is idempotent)
-    for (int o0 = 0; o0 < a.O; o0 += 256) {
+    // many neurons: the lane-ready parameter copies crowd the tiles out of LDS -> slices (each re-gathers the rows;
+    // the in-place clamp is idempotent)
+    const int slice = mfma_slice(a.F, a.E, a.O);
+    for (int o0 = 0; o0 < a.O; o0 += slice) {
         FusedArgs s = a;
-        s.O = a.O - o0 < 256 ? a.O - o0 : 256;
+        s.O = a.O - o0 < slice ? a.O - o0 : slice;
         s.O_out = a.O;
         s.q_fold = a.q_fold + (size_t)o0 * a.E;
         s.values = a.values + (size_t)o0 * a.F;
