@@ -22,7 +22,8 @@ c_i64 = ctypes.POINTER(ctypes.c_int64)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+    srcs = [_SRC, os.path.join(_HERE, "armnet_cpu_twins.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libarmnet_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -272,3 +273,42 @@ def arm_block(variant, ids, vals, sd, alpha, n_iter=50, threads=None):
     if rc != 0:
         raise RuntimeError(f"oracle_arm_block failed: {rc}")
     return out
+
+
+# ---- `_cpu` twins of the C ABI (oracle/armnet_cpu_twins.c): same arguments as include/armnet_hip.h minus the stream ----
+def twin_fold_params(variant, K, H, E, D, bilinear_w, query, bn_weight, bn_bias, bn_mean, bn_var, eps=1e-5):
+    """armnet_fold_params_f32_cpu -> (q_fold [K*H,E], bn_scale [K*H], bn_shift [K*H])"""
+    bw, pbw = _f(bilinear_w); q, pq = _f(query)
+    w, pw = _f(bn_weight); b, pb = _f(bn_bias); m, pm = _f(bn_mean); v, pv = _f(bn_var)
+    qf = np.empty((K * H, E), np.float32); sc = np.empty(K * H, np.float32); sh = np.empty(K * H, np.float32)
+    rc = lib().armnet_fold_params_f32_cpu(int(variant), K, H, E, D, pbw, pq, pw, pb, pm, pv, ctypes.c_float(eps),
+                                          _fp(qf), _fp(sc), _fp(sh))
+    if rc:
+        raise RuntimeError(f"armnet_fold_params_f32_cpu failed: {rc}")
+    return qf, sc, sh
+
+
+def twin_fused_fwd(ids, vals, table, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50, flags=0, rows=None):
+    """armnet_fused_fwd_f32_cpu / armnet_fused_fwd_from_rows_f32_cpu -> (out [B,O,E], id_status); vals clamped in
+    place with flags & 1, like the HIP entry point"""
+    assert vals.dtype == np.float32 and vals.flags["C_CONTIGUOUS"]
+    B, F = vals.shape
+    qf, pqf = _f(q_fold); O, E = qf.shape
+    v2, pv2 = _f(np.asarray(values).reshape(O, F)); sc, psc = _f(bn_scale); sh, psh = _f(bn_shift)
+    out = np.empty((B, O, E), np.float32)
+    status = ctypes.c_int32(0)
+    if rows is not None:
+        r, pr = _f(rows)
+        rc = lib().armnet_fused_fwd_from_rows_f32_cpu(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                                      ctypes.c_uint32(flags), pr, _fp(vals), pqf, pv2, psc, psh, _fp(out))
+    else:
+        ids = np.ascontiguousarray(ids)
+        assert ids.dtype in (np.int64, np.int32)
+        t, pt = _f(table)
+        rc = lib().armnet_fused_fwd_f32_cpu(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                            ctypes.c_uint32(flags), ids.ctypes.data_as(ctypes.c_void_p),
+                                            0 if ids.dtype == np.int64 else 1, _fp(vals), pt, ctypes.c_int64(t.shape[0]),
+                                            pqf, pv2, psc, psh, _fp(out), ctypes.byref(status))
+    if rc:
+        raise RuntimeError(f"armnet_fused_fwd_f32_cpu failed: {rc}")
+    return out, status.value

@@ -468,3 +468,38 @@ def test_integration_md_binding_stub_runs_as_written():
         torch.cuda.synchronize()
     assert _rel_err(got.cpu().numpy().reshape(ref["x_arm"].shape), ref["x_arm"]) <= TOL
     np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])
+
+
+@pytest.mark.parametrize("name", ["g2_criteo_1h_a2.0_stress", "g3_criteo_mh4_a1.7_stress", "g9_criteo_1h_h128_e10_a2.0",
+                                  "g9_movielens_1h_h128_e10_a2.5_ens", "g7_odd_mh2_f22_e11_h20_a1.5"])
+def test_hip_abi_against_its_cpu_twin_on_identical_arguments(name):
+    """ONE set of arguments (raw parameters -> fold -> fused forward) handed to the HIP entry points and to their
+    `_cpu` twins (oracle/armnet_cpu_twins.c): folded parameters and outputs agree"""
+    from armnet_hip import native
+    meta, sd, ids, vals, _ = load(name)
+    c = meta["ctor"]
+    mh = meta["variant"] == "mh"
+    K, H, E, D, F = (c["nhead"] if mh else 1), c["nhid"], c["nemb"], c["d_k"], c["nfield"]
+    O = K * H
+    bw = sd["attn_layer.bilinear_w"] if mh else sd["attn_layer.bilinear_w.weight"]
+    bn = [sd["arm_bn." + k] for k in ("weight", "bias", "running_mean", "running_var")]
+    qf_c, sc_c, sh_c = orc.twin_fold_params(1 if mh else 0, K, H, E, D, bw, sd["attn_layer.query"], *bn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    qf, sc, sh = torch.empty(O, E, device=DEV), torch.empty(O, device=DEV), torch.empty(O, device=DEV)
+    native.fold_params(native.MULTI_HEAD if mh else native.ONE_HEAD, K, H, E, D, t(bw), t(sd["attn_layer.query"]),
+                       *[t(a) for a in bn], 1e-5, qf, sc, sh)
+    assert _rel_err(qf.cpu().numpy(), qf_c) <= 1e-6 and _rel_err(sc.cpu().numpy(), sc_c) <= 1e-6
+    assert _rel_err(sh.cpu().numpy(), sh_c) <= 1e-6
+    g = torch.Generator().manual_seed(77)
+    B = 257
+    ids_b = torch.randint(0, c["nfeat"], (B, F), generator=g)
+    vals_b = torch.rand(B, F, generator=g) * 1.2 - 0.1
+    v_c = vals_b.numpy().copy()
+    want, status = orc.twin_fused_fwd(ids_b.numpy(), v_c, sd["embedding.embedding.weight"], qf_c, sd["attn_layer.values"],
+                                      sc_c, sh_c, float(c["alpha"]), flags=1)
+    v_g = vals_b.clone().to(DEV)
+    out = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd(B, F, E, O, float(c["alpha"]), 50, native.F_WRITE_CLAMPED_VALS, ids_b.to(DEV), v_g,
+                     t(sd["embedding.embedding.weight"]), qf, t(sd["attn_layer.values"]).reshape(O, F).contiguous(), sc, sh, out)
+    assert status == 0 and _rel_err(out.cpu().numpy(), want) <= TOL
+    np.testing.assert_array_equal(v_g.cpu().numpy(), v_c)

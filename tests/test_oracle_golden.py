@@ -67,3 +67,24 @@ def test_out_of_range_id_raises_indexerror():
     bad[0, 0] = sd["embedding.embedding.weight"].shape[0]
     with pytest.raises(IndexError):
         orc.forward("1h", meta["ctor"], sd, bad, vals)
+
+
+@pytest.mark.parametrize("name", [n for n in model_cases() if "train" not in n])
+def test_cpu_twins_of_the_abi_match_the_reference(name):
+    """oracle/armnet_cpu_twins.c: armnet_fold_params_f32_cpu + armnet_fused_fwd_f32_cpu (the ABI's arguments minus the
+    stream, folded parameters, the reference's bisection) against the golden post-BatchNorm neurons"""
+    meta, sd, ids, vals, ref = load(name)
+    c = meta["ctor"]
+    K = c["nhead"] if meta["variant"] == "mh" else 1
+    H, E, D = c["nhid"], c["nemb"], c["d_k"]
+    bw = sd["attn_layer.bilinear_w"] if meta["variant"] == "mh" else sd["attn_layer.bilinear_w.weight"]
+    qf, sc, sh = orc.twin_fold_params(1 if meta["variant"] == "mh" else 0, K, H, E, D, bw, sd["attn_layer.query"],
+                                      sd["arm_bn.weight"], sd["arm_bn.bias"], sd["arm_bn.running_mean"],
+                                      sd["arm_bn.running_var"])
+    v = vals.copy()
+    out, status = orc.twin_fused_fwd(ids, v, sd["embedding.embedding.weight"], qf, sd["attn_layer.values"], sc, sh,
+                                     float(c["alpha"]), flags=1)
+    assert status == 0
+    want = ref["x_arm"].reshape(out.shape)
+    assert float(np.max(np.abs(out - want))) <= 1e-5 * max(1.0, float(np.max(np.abs(want))))
+    np.testing.assert_array_equal(v, ref["vals_clamped"])
