@@ -63,7 +63,8 @@ int armnet_fold_params_f32(int variant, int K, int H, int E, int D, const float*
 int armnet_fused_kernel_kind(int F, int E, int O, float alpha, int n_iter, uint32_t flags) {
     if (F <= 0 || E <= 0 || O <= 0 || n_iter < 0 || !(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     const SparseMapCfg cfg = make_sparse_cfg(alpha, n_iter, F, 1, flags);
-    return (!(flags & ARMNET_F_FORCE_GENERIC) && cfg.mode != SOLVE_BISECT && fused_mfma_supports(F, E, O)) ? 1 : 0;
+    (void)cfg;
+    return (!(flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(F, E, O)) ? 1 : 0;
 }
 
 static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
@@ -72,7 +73,7 @@ static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (!a.vals || !a.q_fold || !a.values || !a.bn_scale || !a.bn_shift || !a.out) return ARMNET_ERR_BAD_ARG;
     if (!(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     a.cfg = make_sparse_cfg(alpha, n_iter, a.F, 1, a.flags);
-    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && a.cfg.mode != SOLVE_BISECT && fused_mfma_supports(a.F, a.E, a.O)) {
+    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(a.F, a.E, a.O)) {
         const int rc = launch_fused_mfma(a, (hipStream_t)stream);
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }

@@ -157,7 +157,7 @@ static int launch_bwd_t(const BwdArgs& a, hipStream_t st) {
 
 int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
-    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && a.cfg.mode != SOLVE_BISECT && fused_bwd_mfma_supports(a.F, a.E, a.O)) {
+    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && fused_bwd_mfma_supports(a.F, a.E, a.O)) {
         const int rc = launch_fused_bwd_mfma(a, st);
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }

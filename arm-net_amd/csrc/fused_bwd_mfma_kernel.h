@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_
             // ---- sparse map: p (normalised) left in the gate registers -------------------------------------
             wave_lds_fence();
             float tau, Ssum = 1.0f;
+            [[maybe_unused]] float tau_hi = 0.f;
             {
                 f32x2 sm2;
 #pragma unroll
@@ -388,6 +389,7 @@ __global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_
                 mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
                 const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
                 if constexpr (MODE == SOLVE_SOFTMAX) tau = mx + (sm - sm);
+                else if constexpr (MODE == SOLVE_BISECT) { tau = (mx - 1.0f) + (sm - sm); tau_hi = mx - tau_off; }
                 else tau = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
             }
             if constexpr (MODE == SOLVE_SOFTMAX) {
@@ -403,6 +405,44 @@ __global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_
                 wave_lds_fence();
                 const Red2 q = red_read(red, 0, c);
                 Ssum = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
+            } else if constexpr (MODE == SOLVE_BISECT) {
+                // the reference's bisection, statement for statement (fused_mfma_kernel.h; utils/entmax.py:49-64)
+                f32x2 pkeep[NP];
+                auto eval = [&](float t_at) -> float {
+                    const f32x2 tk = {t_at, t_at};
+                    f32x2 S2;
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const f32x2 t = pk_sub_clamp01(XP_GET(jp), tk);
+                        f32x2 pv;
+                        pv[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));
+                        pv[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
+                        pkeep[jp] = pv;
+                        S2 = jp == 0 ? pv : S2 + pv;
+                    }
+                    return S2[0] + S2[1];
+                };
+                wave_lds_fence();
+                red_write(red, 0, lane, eval(tau), 0.f);
+                wave_lds_fence();
+                {
+                    const Red2 r = red_read(red, 0, c);
+                    Ssum = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
+                }
+                const float f_lo = Ssum - 1.0f;
+                float dm = tau_hi - tau;
+                for (int it = 0; it < a.cfg.n_iter; ++it) {
+                    wave_lds_fence();
+                    dm *= 0.5f;
+                    const float tm = tau + dm;
+                    red_write(red, 0, lane, eval(tm), 0.f);
+                    wave_lds_fence();
+                    const Red2 r = red_read(red, 0, c);
+                    Ssum = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
+                    tau = ((Ssum - 1.0f) * f_lo >= 0.f) ? tm : tau;
+                }
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) XP_SET(jp, pkeep[jp]);
             } else {
                 f32x2 pkeep[MODE == SOLVE_NEWTON ? NP : 1];
                 for (int it = 0; it < kNewtonMaxIter; ++it) {
@@ -503,6 +543,9 @@ __global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_
                     return pk_mul_clamp01(p2, f32x2{0x1p120f, 0x1p120f});
                 } else if constexpr (MODE == SOLVE_NEWTON15) {
                     return f32x2{__builtin_sqrtf(p2[0]), __builtin_sqrtf(p2[1])};
+                } else if constexpr (MODE == SOLVE_BISECT) {           // any alpha (2 - alpha may be <= 0): select on p > 0
+                    return f32x2{p2[0] > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[0])) : 0.f,
+                                 p2[1] > 0.f ? __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[1])) : 0.f};
                 } else {                                               // log2(0) = -inf -> exp2(-inf) = 0 (alpha < 2)
                     return f32x2{__builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[0])),
                                  __builtin_amdgcn_exp2f(two_m_alpha * __builtin_amdgcn_logf(p2[1]))};
@@ -678,6 +721,7 @@ static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
         case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);           \
         case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);           \
         case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);               \
+        case SOLVE_BISECT: return launch_bwd_one<E, NQ, SOLVE_BISECT, SRC>(a, st);               \
         default: return ARMNET_ERR_UNSUPPORTED;                                                      \
     }
     if (a.id_type == ARMNET_ID_I64) { ARMNET_BWD_MODE(0) }

@@ -23,7 +23,8 @@
 //   map       elements per instruction: t = clamp01(x - tau) is ONE v_pk_add_f32 with the neg and
 //             clamp modifiers (x - tau <= 1 always holds because tau >= max - 1).  A row is spread
 //             over the 4 lane groups g: partial sums meet through a 1 KiB LDS scratch.
-//             alpha = 2: Michelot (= Newton from the left, finite), alpha = 1.5 / generic: Newton.
+//             alpha = 2: Michelot (= Newton from the left, finite), alpha = 1.5 / generic: Newton;
+//             alpha > 2, n_iter < 24, ARMNET_F_FAITHFUL_BISECT: the reference's bisection, literally.
 //   MFMA #2   Z^T[e, o] = sum_f X[f, e] * W[o, f]:  the C layout of MFMA #1 IS the B-operand layout
 //             of MFMA #2 (k = lane group g <-> field 4j+g): the weights never move.
 //   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte store per lane
@@ -436,6 +437,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             }
             wave_lds_fence();
             float tau[SPW], Ssum[SPW];
+            float tau_hi[MODE == SOLVE_BISECT ? SPW : 1];
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
                 const Red2 r = red_read(red, s & 1, c);
@@ -443,6 +445,9 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
                 if constexpr (MODE == SOLVE_SOFTMAX) {
                     tau[s] = mx + (sm - sm);                // NaN / inf anywhere -> NaN row
+                } else if constexpr (MODE == SOLVE_BISECT) {
+                    tau[s] = (mx - 1.0f) + (sm - sm);       // tau_lo (entmax.py:46); NaN / inf anywhere -> NaN row
+                    tau_hi[s] = mx - tau_off;               // entmax.py:47
                 } else {
                     // tau0 = max(mx - 1, mean - d^-(alpha-1)) <= root; NaN/inf gates poison the row
                     tau[s] = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
@@ -469,6 +474,60 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                     const Red2 q = red_read(red, s & 1, c);
                     Ssum[s] = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
                 }
+            } else if constexpr (MODE == SOLVE_BISECT) {
+                // The reference's bisection, statement for statement (utils/entmax.py:49-64), for alpha > 2, n_iter < 24
+                // and ARMNET_F_FAITHFUL_BISECT: f_lo at tau_lo, then n_iter halvings; p is the one of the LAST tau_m.
+                // t^(1/(alpha-1)) through the hardware log2/exp2 pair (2 transcendentals per element and step).
+                f32x2 pkeep[SPW * NP];
+                float f_lo[SPW], dm[SPW];
+                auto eval = [&](int s_, float t_at) -> float {          // p(t_at) into pkeep, partial row sum
+                    const f32x2 tk = {t_at, t_at};
+                    f32x2 S2;
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const f32x2 t = pk_sub_clamp01(XP_GET(s_, jp), tk);     // tau >= max - 1  =>  x - tau <= 1
+                        f32x2 pv;
+                        pv[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));   // log2(0) = -inf -> 0
+                        pv[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
+                        pkeep[s_ * NP + jp] = pv;
+                        S2 = jp == 0 ? pv : S2 + pv;
+                    }
+                    return S2[0] + S2[1];
+                };
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) red_write(red, s & 1, lane, eval(s, tau[s]), 0.f);
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    const Red2 r = red_read(red, s & 1, c);
+                    Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
+                    f_lo[s] = Ssum[s] - 1.0f;
+                    dm[s] = tau_hi[s] - tau[s];
+                }
+                for (int it = 0; it < a.cfg.n_iter; ++it) {
+                    float tm[SPW];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        dm[s] *= 0.5f;
+                        tm[s] = tau[s] + dm[s];
+                        red_write(red, s & 1, lane, eval(s, tm[s]), 0.f);
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const Red2 r = red_read(red, s & 1, c);
+                        Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
+                        const float f_m = Ssum[s] - 1.0f;
+                        tau[s] = (f_m * f_lo[s] >= 0.f) ? tm[s] : tau[s];
+                    }
+                }
+                PHASE(3);
+#pragma unroll
+                for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) XP_SET(s, jp, pkeep[s * NP + jp] * VV(jp));
             } else {
                 // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
                 // they converge.  When the loop ends every row's S was evaluated at its final threshold.
@@ -640,7 +699,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
     // generic-alpha Newton keeps two transcendental temporaries per pair alive)
     constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
-                        : (E >= 32 || MODE == SOLVE_NEWTON) ? 3      // measured: nemb=32 is faster at 3
+                        : (E >= 32 || MODE == SOLVE_NEWTON || MODE == SOLVE_BISECT) ? 3      // measured: nemb=32 is faster at 3
                         : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
                         : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
@@ -679,6 +738,7 @@ static int launch_mode(const FusedArgs& a, hipStream_t st) {
         case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);
         case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);
         case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);
+        case SOLVE_BISECT: return launch_one<E, NQ, SOLVE_BISECT, SRC>(a, st);
         default: return ARMNET_ERR_UNSUPPORTED;
     }
 }

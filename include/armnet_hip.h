@@ -98,8 +98,9 @@ int armnet_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter
 
 /*
  * Which kernel the fused calls above run for a shape: 1 = the matrix-core (MFMA) kernel, 0 = the generic
- * thread-per-row kernel (nemb < 4 or > 64, nfield > 48, > 1024 neurons, alpha > 2, n_iter < 24,
- * ARMNET_F_FAITHFUL_BISECT / ARMNET_F_FORCE_GENERIC), negative = armnet_status.  Host-only, no GPU work.
+ * thread-per-row kernel (nemb < 4 or > 64, nfield > 48, > 1024 neurons, ARMNET_F_FORCE_GENERIC), negative =
+ * armnet_status.  Host-only, no GPU work.  (The reference's literal bisection — alpha > 2, n_iter < 24,
+ * ARMNET_F_FAITHFUL_BISECT — is a solver mode of the matrix-core kernel.)
  * Buffers need only their natural alignment (4 bytes for floats / int32, 8 for int64 ids).
  */
 int armnet_fused_kernel_kind(int F, int E, int O, float alpha, int n_iter, uint32_t flags);

@@ -338,6 +338,14 @@ def run_sh_grad_cases():
     grad_case("h2_grad_movielens_1h_h128_e10_a2.0_evalbn", "1h", base(3, 200, 10, 2.0, 128, mlp_nhid=16), 16, 105, False)
     grad_case("h2_grad_frappe_mh4_h4_e10_a1.5_ens_train", "mh",
               base(10, 200, 10, 1.5, 4, nhead=4, ensemble=True, mlp_nhid=16, deep_nhid=16), 16, 106, True)
+    alpha25_grad_cases()
+
+
+def alpha25_grad_cases():
+    """alpha = 2.5 (run.sh:11,37): the sparse map is the literal bisection, forward and backward"""
+    grad_case("h2_grad_movielens_1h_h128_e10_a2.5_ens_train", "1h",
+              base(3, 200, 10, 2.5, 128, ensemble=True, mlp_nhid=16, deep_nhid=16), 16, 107, True)
+    grad_case("h2_grad_criteo_1h_h32_e16_a2.5_evalbn", "1h", base(39, 200, 16, 2.5, 32, mlp_nhid=16), 16, 108, False)
 
 
 def entmax_grad_cases():
@@ -368,6 +376,8 @@ if __name__ == "__main__":
         entmax_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":
         run_sh_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--alpha25-grad-only":
+        alpha25_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--more-only":
         more_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-only":     # add the G9 cases without rewriting the others

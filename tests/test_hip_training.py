@@ -81,7 +81,9 @@ BWD_SWEEP = [(1, 4, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5
              (17, 20, 5, 2.0), (22, 32, 32, 2.0), (22, 10, 64, 1.5), (25, 28, 70, 1.5), (31, 32, 64, 1.0),
              (39, 16, 32, 2.0), (39, 16, 32, 1.5), (39, 16, 32, 1.7), (39, 16, 32, 1.0), (39, 10, 128, 2.0),
              (43, 10, 96, 1.7), (47, 8, 19, 2.0), (48, 64, 24, 2.0), (39, 64, 32, 1.5), (30, 40, 20, 1.7), (6, 60, 7, 1.0),
-             (39, 5, 32, 2.0), (10, 7, 20, 1.5), (22, 9, 16, 1.7), (43, 15, 9, 1.0), (24, 33, 16, 1.5), (39, 63, 12, 2.0)]
+             (39, 5, 32, 2.0), (10, 7, 20, 1.5), (22, 9, 16, 1.7), (43, 15, 9, 1.0), (24, 33, 16, 1.5), (39, 63, 12, 2.0),
+             # alpha > 2: the literal bisection as a solver mode of the matrix-core kernels
+             (39, 16, 32, 2.5), (3, 10, 128, 2.5), (22, 32, 20, 3.0), (10, 10, 40, 2.2)]
 
 
 @pytest.mark.parametrize("F,E,O,alpha", BWD_SWEEP)
@@ -111,8 +113,10 @@ def test_mfma_backward_agrees_with_the_generic_backward(F, E, O, alpha):
     got32 = run(0, ids.to(torch.int32))
     for name, a, b, c in zip(("d_table", "d_values", "d_qfold"), got, want, got32):
         scale = max(float(b.abs().max()), 1e-12)
-        assert float((a - b).abs().max()) / scale <= 2e-5, name
-        assert float((c - b).abs().max()) / scale <= 2e-5, name + " (int32 ids)"
+        # alpha > 2: p^(2 - alpha) is unbounded as p -> 0+ and amplifies the two kernels' different pow forms
+        tol = 2e-4 if alpha > 2.0 else 2e-5
+        assert float((a - b).abs().max()) / scale <= tol, name
+        assert float((c - b).abs().max()) / scale <= tol, name + " (int32 ids)"
 
 
 @pytest.mark.parametrize("shape,relu", [((64, 32, 16), False), ((37, 7, 10), False), ((1000, 256), True),

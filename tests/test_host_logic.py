@@ -67,9 +67,11 @@ def test_kernel_selection_covers_the_reference_run_sh_shapes():
         assert k(F, 10, O, 2.0) == 1 and k(F, 10, O, 1.5) == 1 and k(F, 10, O, 1.7) == 1 and k(F, 10, O, 1.0) == 1
     for F, E, O in [(10, 10, 10), (39, 16, 32), (39, 16, 128), (39, 64, 32), (22, 32, 128)]:   # BASELINE.json configs
         assert k(F, E, O, 2.0) == 1
-    assert k(39, 10, 128, 2.5) == 0                               # alpha > 2: the faithful bisection
-    assert k(39, 10, 128, 2.0, n_iter=10) == 0                    # too few iterations to have converged
-    assert k(39, 10, 128, 2.0, flags=native.F_FAITHFUL_BISECT) == 0
+    # the reference's literal bisection (alpha > 2, too few iterations to have converged, the faithful flag) is a
+    # solver mode of the same kernel
+    assert k(39, 10, 128, 2.5) == 1 and k(3, 10, 128, 2.5) == 1
+    assert k(39, 10, 128, 2.0, n_iter=10) == 1
+    assert k(39, 10, 128, 2.0, flags=native.F_FAITHFUL_BISECT) == 1
     assert k(39, 10, 128, 2.0, flags=native.F_FORCE_GENERIC) == 0
     assert k(39, 11, 128, 2.0) == 1 and k(39, 3, 128, 2.0) == 0 and k(39, 2, 128, 2.0) == 0 and k(39, 128, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
     with pytest.raises(native.ArmnetNativeError):

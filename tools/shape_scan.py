@@ -15,7 +15,7 @@ bad = n = 0
 for F in range(1, 49):
     for E in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 20, 31, 32, 33, 48, 63, 64):
         for O in (1, 7, 16, 24, 32, 40, 70):
-            for alpha in (1.0, 1.5, 1.7, 2.0):
+            for alpha in (1.0, 1.5, 1.7, 2.0) + ((2.5,) if (F + E + O) % 5 == 0 else ()):
                 if native.fused_kernel_kind(F, E, O, alpha) != 1:
                     continue
                 g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
@@ -42,7 +42,9 @@ for F in range(1, 49):
                         outs.append((dt, dv, dq))
                     for nm, a, b in zip(("d_table", "d_values", "d_qfold"), outs[1], outs[0]):
                         e2 = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
-                        if not (e2 <= 5e-5):
+                        # alpha > 2: gppr = p^(2 - alpha) grows without bound as p -> 0+, so the ~2e-7 difference between
+                        # the kernels' pow forms (libm powf vs exp2/log2) is amplified; the reference-gradient fixtures pin it
+                        if not (e2 <= (5e-3 if alpha > 2.0 else 5e-5)):
                             bad += 1
                             print(f"BWD mismatch F={F} E={E} O={O} alpha={alpha} {nm}: {e2}")
 print(f"{n} shapes scanned, {bad} disagreements")
