@@ -435,11 +435,13 @@ __global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_
                     wave_lds_fence();
                     dm *= 0.5f;
                     const float tm = tau + dm;
+                    const bool moving = !(tm == tau);
                     red_write(red, 0, lane, eval(tm), 0.f);
                     wave_lds_fence();
                     const Red2 r = red_read(red, 0, c);
                     Ssum = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
                     tau = ((Ssum - 1.0f) * f_lo >= 0.f) ? tm : tau;
+                    if (!__builtin_amdgcn_ballot_w64(moving)) break;        // settled everywhere: later steps repeat this one
                 }
 #pragma unroll
                 for (int jp = 0; jp < NP; ++jp) XP_SET(jp, pkeep[jp]);

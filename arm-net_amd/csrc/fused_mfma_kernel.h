@@ -507,11 +507,13 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 }
                 for (int it = 0; it < a.cfg.n_iter; ++it) {
                     float tm[SPW];
+                    bool moving = false;
                     wave_lds_fence();
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         dm[s] *= 0.5f;
                         tm[s] = tau[s] + dm[s];
+                        moving |= !(tm[s] == tau[s]);                       // NaN rows never settle: all n_iter steps
                         red_write(red, s & 1, lane, eval(s, tm[s]), 0.f);
                     }
                     wave_lds_fence();
@@ -522,6 +524,9 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                         const float f_m = Ssum[s] - 1.0f;
                         tau[s] = (f_m * f_lo[s] >= 0.f) ? tm[s] : tau[s];
                     }
+                    // once tau_lo + dm rounds to tau_lo in every row of the wave (dm below half an ulp: ~25 steps),
+                    // every later step would evaluate the same tau_m again: stopping here is bit-identical
+                    if (!__builtin_amdgcn_ballot_w64(moving)) break;
                 }
                 PHASE(3);
 #pragma unroll
