@@ -143,6 +143,9 @@ __device__ inline void sparse_map_row(float* x, int stride, int d, const SparseM
         for (int it = 0; it < c.n_iter; ++it) {   // entmax.py:53-61
             dm *= 0.5f;
             tau_m = tau_lo + dm;
+            // dm below half an ulp of tau_lo: this and every later step evaluate tau_lo again — the final evaluation
+            // below does it once more, so leaving here is bit-identical to running all n_iter steps
+            if (tau_m == tau_lo) break;
             float s = 0.f;
             for (int i = 0; i < d; ++i) s += powf(clamp_min0(x[i * stride] - tau_m), c.r);
             const float f_m = s - 1.0f;
