@@ -178,7 +178,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         while S < 64 and B % (2 * S) == 0 and B // (2 * S) >= 1024:
             S *= 2
         if S > 1:
-            dw = torch.bmm(dy.view(S, B // S, -1).transpose(1, 2), x.view(S, B // S, -1)).sum(0)
+            dw = torch.bmm(dy.reshape(S, B // S, -1).transpose(1, 2), x.reshape(S, B // S, -1)).sum(0)
         else:
             dw = dy.t() @ x
         return dx, dw, dy.sum(0)
@@ -214,10 +214,11 @@ class HipEmbedding(nn.Module):
         nn.init.xavier_uniform_(self.embedding.weight)
         self.check_ids = True
 
-    def forward(self, x):
+    def forward(self, x, check_ids=None):
+        check = self.check_ids if check_ids is None else check_ids
         if torch.is_grad_enabled() and self.embedding.weight.requires_grad:
-            return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], self.check_ids)
-        return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=self.check_ids)
+            return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], check)
+        return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=check)
 
 
 def build_mlp(ninput, nlayers, nhid, dropout, noutput=1):
@@ -280,8 +281,9 @@ class ArmNetBase(nn.Module):
     def _d_k(self):
         raise NotImplementedError
 
-    def arm_block(self, ids, vals):
-        """ids [B,F], vals [B,F] (clamped in place) -> post-BN exponential neurons [B, O, E].
+    def arm_block(self, ids, vals, out=None):
+        """ids [B,F], vals [B,F] (clamped in place) -> post-BN exponential neurons [B, O, E]
+        (written into `out` when given: inference with a replicated table only).
 
         Inference (eval mode under no_grad, or frozen parameters): ONE fused kernel, BN folded.
         Otherwise (training, or eval with autograd on): the same kernel yields the pre-BN neurons inside
@@ -311,23 +313,63 @@ class ArmNetBase(nn.Module):
                                       self.arm_bn)
         if getattr(self, "_shard", None) is not None:
             from .sharded import sharded_arm_block
+            self._refresh_shard()
             return sharded_arm_block(self._shard, ids, vals, qf, at.values, sc, sh, self.alpha, n_iter=self.n_iter,
-                                     write_clamped_vals=True, flags=self.kernel_flags)
+                                     write_clamped_vals=True, flags=self.kernel_flags, check_ids=self.check_ids)
         return arm_block_forward(ids, vals, self.embedding.embedding.weight, qf, at.values, sc, sh, self.alpha,
                                  n_iter=self.n_iter, write_clamped_vals=True, check_ids=self.check_ids,
-                                 flags=self.kernel_flags)
+                                 flags=self.kernel_flags, out=out)
 
-    def shard_embedding(self, group=None):
+    def shard_embedding(self, group=None, release_full=False):
         """Row-shard the ARM embedding table over the process group (multi-GPU): this rank
-        keeps rows i = rank (mod world); every later arm_block() call fetches rows by all-to-all.
-        The full table must be resident when this is called (it is released afterwards)."""
+        keeps a COPY of rows i = rank (mod world); every later inference arm_block() call fetches rows by
+        all-to-all.  The full table must be resident when this is called.
+
+        The full parameter `embedding.embedding.weight` stays resident by default (state_dict, training and
+        un-sharding keep working) and the shard is re-cut whenever the parameter changes (load_state_dict, an
+        optimizer step: tracked by its storage pointer and version counter; writes through `.data` are not
+        seen — call shard_embedding() again after those).  With release_full=True the parameter's storage is
+        replaced by an empty [0, nemb] tensor afterwards — that is what frees the memory; the shard is then the
+        only copy (state_dict no longer holds the table)."""
         import torch.distributed as dist
         from .sharded import RowShardedTable, shard_rows
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        w = self.embedding.embedding.weight.detach()
+        p = self.embedding.embedding.weight
+        w = p.detach()
         self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group)
+        self._shard_src = None if release_full else (p.data_ptr(), p._version)
+        if release_full:
+            p.data = torch.empty(0, w.shape[1], device=w.device, dtype=w.dtype)
         return self
+
+    def _refresh_shard(self):
+        """re-cut the local shard when the full table changed since shard_embedding() (no-op after release_full)"""
+        src = getattr(self, "_shard_src", None)
+        if src is None:
+            return
+        p = self.embedding.embedding.weight
+        if (p.data_ptr(), p._version) != src:
+            from .sharded import shard_rows
+            sh = self._shard
+            sh.table_local = shard_rows(p.detach(), sh.rank, sh.world)
+            self._shard_src = (p.data_ptr(), p._version)
+
+    def invalidate_folded(self):
+        """Drop every cached parameter fold (q_fold, the BatchNorm affines, the MLPs' folded / split weights).
+        The caches key on (storage pointer, version counter) of their sources, which catches optimizer steps,
+        load_state_dict and in-place ops — but NOT writes through `.data` (p.data.copy_(), some EMA /
+        weight-averaging utilities): call this after such a write.  train()/eval() call it too."""
+        self._folded.key = None
+        for m in self.modules():
+            if isinstance(m, _MLP):
+                m.invalidate()
+        if getattr(self, "_shard", None) is not None and getattr(self, "_shard_src", None) is not None:
+            self._shard_src = (0, -1)
+
+    def train(self, mode=True):
+        self.invalidate_folded()
+        return super().train(mode)
 
     def make_graphed(self, ids, vals):
         """Capture this model's inference forward for the shape of (ids, vals) in a hipGraph."""
@@ -347,8 +389,8 @@ class ArmNetBase(nn.Module):
             v.copy_(v_run)                                       # keep the visible clamp side effect
         y = self.mlp(x_arm.view(x_arm.shape[0], -1))            # [B, noutput]
         if hasattr(self, "ensemble_layer"):
-            self.deep_embedding.check_ids = False                # ids were validated by the fused call
-            x_deep = self.deep_embedding({"id": ids, "value": v})  # sees the clamped values (armnet.py:94)
+            # ids were validated by the fused call; sees the clamped values (armnet.py:94)
+            x_deep = self.deep_embedding({"id": ids, "value": v}, check_ids=False)
             y_deep = self.deep_mlp(x_deep.view(x_deep.shape[0], -1))
             yy = torch.cat([y, y_deep], dim=1)
             if self.training and yy.shape[0] >= 2048:           # tiny-N, huge-K weight gradient: split-K
@@ -414,20 +456,21 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep captures the training path: call model.train() first")
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.ids, self.vals, self.y = ids.clone(), vals.clone(), y.clone()
-        self._check = model.check_ids
+        check = model.check_ids
         model.check_ids = False                     # no host sync inside a capture
-        if hasattr(model, "deep_embedding"):
-            model.deep_embedding.check_ids = False
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager(zero=False)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager(zero=False)
+        finally:
+            model.check_ids = check                 # later eager calls validate ids again
 
     def _eager(self, zero=True):
         if zero:
@@ -463,6 +506,15 @@ class _MLP(nn.Module):
         self._fold_key = None
         self._folded = None
         self.fold_eval = True
+
+    def eval_path(self):
+        """which code runs the eval-mode head (reported by bench.py)"""
+        return "torch/hipBLASLt fp32 GEMMs, BatchNorm folded into the weights, bias+ReLU epilogue"
+
+    def invalidate(self):
+        """forget the folded eval-mode weights (see ArmNetBase.invalidate_folded)"""
+        self._fold_key = None
+        self._folded = None
 
     def _fold(self):
         mods = list(self.mlp)

@@ -89,6 +89,35 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _on:
+    """Device guard of one native call: every tensor argument must live on ONE HIP device; that device is made
+    current for the duration of the call, so that `_stream()`, the library's CU-count query and its
+    hipFuncSetAttribute calls all act on the device that owns the pointers (torch ops get this from their own
+    DeviceGuard; raw ctypes launches do not)."""
+
+    def __init__(self, *tensors):
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise ArmnetNativeError(f"expected a tensor on the HIP device, got one on {t.device} (no CPU fallback)")
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise ArmnetNativeError(f"tensor arguments live on different devices ({dev} and {t.device})")
+        if dev is None:
+            raise ArmnetNativeError("no device tensor among the arguments")
+        self._ctx = torch.cuda.device(dev)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
 def _dev_f32(t, name):
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise ArmnetNativeError(f"{name}: expected a contiguous float32 tensor on the HIP device, got "
@@ -106,13 +135,13 @@ def _id_type(ids):
 
 def fold_params(variant, K, H, E, D, bilinear_w, query, bn_w, bn_b, bn_mean, bn_var, eps,
                 q_fold, bn_scale, bn_shift):
-    for n, t in (("bilinear_w", bilinear_w), ("query", query), ("bn_w", bn_w), ("bn_b", bn_b),
-                 ("bn_mean", bn_mean), ("bn_var", bn_var), ("q_fold", q_fold), ("bn_scale", bn_scale),
-                 ("bn_shift", bn_shift)):
+    ts = (bilinear_w, query, bn_w, bn_b, bn_mean, bn_var, q_fold, bn_scale, bn_shift)
+    for n, t in zip(("bilinear_w", "query", "bn_w", "bn_b", "bn_mean", "bn_var", "q_fold", "bn_scale", "bn_shift"), ts):
         _dev_f32(t, n)
-    check(load().armnet_fold_params_f32(variant, K, H, E, D, _ptr(bilinear_w), _ptr(query), _ptr(bn_w),
-                                        _ptr(bn_b), _ptr(bn_mean), _ptr(bn_var), ctypes.c_float(eps),
-                                        _ptr(q_fold), _ptr(bn_scale), _ptr(bn_shift), _stream()))
+    with _on(*ts):
+        check(load().armnet_fold_params_f32(variant, K, H, E, D, _ptr(bilinear_w), _ptr(query), _ptr(bn_w),
+                                            _ptr(bn_b), _ptr(bn_mean), _ptr(bn_var), ctypes.c_float(eps),
+                                            _ptr(q_fold), _ptr(bn_scale), _ptr(bn_shift), _stream()))
 
 
 def fused_kernel_kind(F, E, O, alpha, n_iter=50, flags=0):
@@ -124,104 +153,117 @@ def fused_kernel_kind(F, E, O, alpha, n_iter=50, flags=0):
     return rc
 
 
-def fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, bn_scale, bn_shift, out,
-              id_status=None):
+def _ids_ok(ids):
     if not (ids.is_cuda and ids.is_contiguous()):
         raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
-    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values),
-                 ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("out", out)):
+    return ids
+
+
+def fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, bn_scale, bn_shift, out,
+              id_status=None):
+    _ids_ok(ids)
+    ts = (vals, table, q_fold, values, bn_scale, bn_shift, out)
+    for n, t in zip(("vals", "table", "q_fold", "values", "bn_scale", "bn_shift", "out"), ts):
         _dev_f32(t, n)
-    check(load().armnet_fused_fwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
-                                      ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
-                                      ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values),
-                                      _ptr(bn_scale), _ptr(bn_shift), _ptr(out), _ptr(id_status), _stream()))
+    with _on(ids, id_status, *ts):
+        check(load().armnet_fused_fwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                          ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                          ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values),
+                                          _ptr(bn_scale), _ptr(bn_shift), _ptr(out), _ptr(id_status), _stream()))
 
 
 def fused_fwd_from_rows(B, F, E, O, alpha, n_iter, flags, rows, vals, q_fold, values, bn_scale, bn_shift, out):
-    for n, t in (("rows", rows), ("vals", vals), ("q_fold", q_fold), ("values", values),
-                 ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("out", out)):
+    ts = (rows, vals, q_fold, values, bn_scale, bn_shift, out)
+    for n, t in zip(("rows", "vals", "q_fold", "values", "bn_scale", "bn_shift", "out"), ts):
         _dev_f32(t, n)
-    check(load().armnet_fused_fwd_from_rows_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
-                                                ctypes.c_uint32(flags), _ptr(rows), _ptr(vals), _ptr(q_fold),
-                                                _ptr(values), _ptr(bn_scale), _ptr(bn_shift), _ptr(out),
-                                                _stream()))
+    with _on(*ts):
+        check(load().armnet_fused_fwd_from_rows_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                                    ctypes.c_uint32(flags), _ptr(rows), _ptr(vals), _ptr(q_fold),
+                                                    _ptr(values), _ptr(bn_scale), _ptr(bn_shift), _ptr(out),
+                                                    _stream()))
 
 
 def gather_scale(n_rows, E, ids, vals, table, out, id_status=None):
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    _ids_ok(ids)
     _dev_f32(table, "table"); _dev_f32(out, "out")
     if vals is not None:
         _dev_f32(vals, "vals")
-    check(load().armnet_gather_scale_f32(ctypes.c_int64(n_rows), E, _ptr(ids), _id_type(ids), _ptr(vals),
-                                         _ptr(table), ctypes.c_int64(table.shape[0]), _ptr(out),
-                                         _ptr(id_status), _stream()))
+    with _on(ids, vals, table, out, id_status):
+        check(load().armnet_gather_scale_f32(ctypes.c_int64(n_rows), E, _ptr(ids), _id_type(ids), _ptr(vals),
+                                             _ptr(table), ctypes.c_int64(table.shape[0]), _ptr(out),
+                                             _ptr(id_status), _stream()))
 
 
 def clamp_vals(vals):
     _dev_f32(vals, "vals")
-    check(load().armnet_clamp_vals_f32(_ptr(vals), ctypes.c_int64(vals.numel()), _stream()))
+    with _on(vals):
+        check(load().armnet_clamp_vals_f32(_ptr(vals), ctypes.c_int64(vals.numel()), _stream()))
 
 
 def entmax(rows, d, alpha, n_iter, ensure_sum_one, flags, X, P):
     _dev_f32(X, "X"); _dev_f32(P, "P")
-    check(load().armnet_entmax_f32(ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
-                                   int(bool(ensure_sum_one)), ctypes.c_uint32(flags), _ptr(X), _ptr(P), _stream()))
+    with _on(X, P):
+        check(load().armnet_entmax_f32(ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
+                                       int(bool(ensure_sum_one)), ctypes.c_uint32(flags), _ptr(X), _ptr(P), _stream()))
 
 
 def shard_route_ws_bytes(n, R):
     return int(load().armnet_shard_route_ws_bytes(ctypes.c_int64(n), int(R)))
 
 
-def shard_route_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_status=None):
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
-    for name, t in (("counts", counts), ("send_local", send_local), ("perm", perm)):
+def _i32_ok(**ts):
+    for name, t in ts.items():
         if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
             raise ArmnetNativeError(f"{name}: expected a contiguous int32 tensor on the HIP device")
-    check(load().armnet_shard_route_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat),
-                                        _ptr(counts), _ptr(send_local), _ptr(perm), _ptr(workspace),
-                                        ctypes.c_int64(workspace.numel() * workspace.element_size()),
-                                        _ptr(id_status), _stream()))
+
+
+def shard_route_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_status=None):
+    _ids_ok(ids)
+    _i32_ok(counts=counts, send_local=send_local, perm=perm)
+    with _on(ids, counts, send_local, perm, workspace, id_status):
+        check(load().armnet_shard_route_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat),
+                                            _ptr(counts), _ptr(send_local), _ptr(perm), _ptr(workspace),
+                                            ctypes.c_int64(workspace.numel() * workspace.element_size()),
+                                            _ptr(id_status), _stream()))
 
 
 def fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, z, dz, d_table, d_values, d_qfold):
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
-    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values), ("z", z), ("dz", dz),
-                 ("d_table", d_table), ("d_values", d_values), ("d_qfold", d_qfold)):
+    _ids_ok(ids)
+    ts = (vals, table, q_fold, values, z, dz, d_table, d_values, d_qfold)
+    for n, t in zip(("vals", "table", "q_fold", "values", "z", "dz", "d_table", "d_values", "d_qfold"), ts):
         _dev_f32(t, n)
-    check(load().armnet_fused_bwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
-                                      ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
-                                      ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
-                                      _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+    with _on(ids, *ts):
+        check(load().armnet_fused_bwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                          ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                          ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dz),
+                                          _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
 
 
 def scatter_add(ids, vals, grad, d_table):
     """d_table[ids[r], :] += grad[r, :] * vals[r] (backward of gather_scale with respect to the table)"""
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
+    _ids_ok(ids)
     _dev_f32(grad, "grad"); _dev_f32(d_table, "d_table")
     if vals is not None:
         _dev_f32(vals, "vals")
     n, E = ids.numel(), d_table.shape[1]
-    check(load().armnet_scatter_add_f32(ctypes.c_int64(n), E, _ptr(ids), _id_type(ids), _ptr(vals), _ptr(grad),
-                                        ctypes.c_int64(d_table.shape[0]), _ptr(d_table), _stream()))
+    with _on(ids, vals, grad, d_table):
+        check(load().armnet_scatter_add_f32(ctypes.c_int64(n), E, _ptr(ids), _id_type(ids), _ptr(vals), _ptr(grad),
+                                            ctypes.c_int64(d_table.shape[0]), _ptr(d_table), _stream()))
 
 
 def fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, z, dy, coefA, coefB, coefC,
                  d_table, d_values, d_qfold):
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
-    for n, t in (("vals", vals), ("table", table), ("q_fold", q_fold), ("values", values), ("z", z), ("dy", dy),
-                 ("coefA", coefA), ("coefB", coefB), ("coefC", coefC),
-                 ("d_table", d_table), ("d_values", d_values), ("d_qfold", d_qfold)):
+    _ids_ok(ids)
+    ts = (vals, table, q_fold, values, z, dy, coefA, coefB, coefC, d_table, d_values, d_qfold)
+    for n, t in zip(("vals", "table", "q_fold", "values", "z", "dy", "coefA", "coefB", "coefC", "d_table", "d_values",
+                     "d_qfold"), ts):
         _dev_f32(t, n)
-    check(load().armnet_fused_bwd_bn_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
-                                         ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
-                                         ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z), _ptr(dy),
-                                         _ptr(coefA), _ptr(coefB), _ptr(coefC),
-                                         _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
+    with _on(ids, *ts):
+        check(load().armnet_fused_bwd_bn_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                             ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                             ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(z),
+                                             _ptr(dy), _ptr(coefA), _ptr(coefB), _ptr(coefC),
+                                             _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
 
 
 def _ncl(x):
@@ -236,17 +278,17 @@ def bn_forward_train(x, weight, bias, running_mean, running_var, momentum, eps, 
     """training-mode BatchNorm1d forward (+ optional ReLU): returns y, mean, rstd, scale, shift"""
     _dev_f32(x, "x")
     N, C, L = _ncl(x)
-    dev = x.device
-    buf = torch.zeros(6, C, device=dev, dtype=torch.float32)      # stats[2], mean, rstd, scale, shift
-    st = _stream()
-    lib = load()
-    check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
-    check(lib.armnet_bn_finalize_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(x), L, _ptr(weight), _ptr(bias),
-                                     ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
-                                     _ptr(running_var), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), st))
-    y = torch.empty_like(x)
-    check(lib.armnet_bn_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf[4]), _ptr(buf[5]), int(bool(relu)),
-                                  _ptr(y), st))
+    with _on(x, weight, bias, running_mean, running_var):
+        buf = torch.zeros(6, C, device=x.device, dtype=torch.float32)      # stats[2], mean, rstd, scale, shift
+        st = _stream()
+        lib = load()
+        check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
+        check(lib.armnet_bn_finalize_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(x), L, _ptr(weight), _ptr(bias),
+                                         ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
+                                         _ptr(running_var), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), st))
+        y = torch.empty_like(x)
+        check(lib.armnet_bn_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf[4]), _ptr(buf[5]), int(bool(relu)),
+                                      _ptr(y), st))
     return y, buf[2], buf[3], buf[4], buf[5]
 
 
@@ -255,21 +297,23 @@ def bn_backward_coef(x, dy, weight, mean, rstd, relu_scale=None, relu_shift=None
     dx = coefA * dy + coefC * x + coefB (dy masked by the recomputed ReLU when relu_scale/shift are given)"""
     _dev_f32(x, "x"); _dev_f32(dy, "dy")
     N, C, L = _ncl(x)
-    buf = torch.zeros(7, C, device=x.device, dtype=torch.float32)   # sums[2], d_weight, d_bias, A, B, C
-    st = _stream()
-    lib = load()
-    check(lib.armnet_bn_bwd_reduce_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd),
-                                       _ptr(relu_scale), _ptr(relu_shift), _ptr(buf), st))
-    check(lib.armnet_bn_bwd_coef_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(weight), _ptr(mean), _ptr(rstd),
-                                     _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), _ptr(buf[6]), st))
+    with _on(x, dy, weight, mean, rstd, relu_scale, relu_shift):
+        buf = torch.zeros(7, C, device=x.device, dtype=torch.float32)   # sums[2], d_weight, d_bias, A, B, C
+        st = _stream()
+        lib = load()
+        check(lib.armnet_bn_bwd_reduce_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd),
+                                           _ptr(relu_scale), _ptr(relu_shift), _ptr(buf), st))
+        check(lib.armnet_bn_bwd_coef_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(weight), _ptr(mean), _ptr(rstd),
+                                         _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), _ptr(buf[6]), st))
     return buf[2], buf[3], buf[4], buf[5], buf[6]
 
 
 def bn_backward_apply(x, dy, coefA, coefB, coefC, relu_scale=None, relu_shift=None):
     N, C, L = _ncl(x)
-    dx = torch.empty_like(x)
-    check(load().armnet_bn_bwd_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(coefA), _ptr(coefB),
-                                         _ptr(coefC), _ptr(relu_scale), _ptr(relu_shift), _ptr(dx), _stream()))
+    with _on(x, dy, coefA, coefB, coefC, relu_scale, relu_shift):
+        dx = torch.empty_like(x)
+        check(load().armnet_bn_bwd_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(dy), _ptr(coefA), _ptr(coefB),
+                                             _ptr(coefC), _ptr(relu_scale), _ptr(relu_shift), _ptr(dx), _stream()))
     return dx
 
 
@@ -278,13 +322,11 @@ def shard_route_unique_ws_bytes(R, nfeat):
 
 
 def shard_route_unique_ids(n, ids, R, nfeat, counts, send_local, perm, workspace, id_status=None):
-    if not (ids.is_cuda and ids.is_contiguous()):
-        raise ArmnetNativeError("ids must be a contiguous tensor on the HIP device")
-    for name, t in (("counts", counts), ("send_local", send_local), ("perm", perm)):
-        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
-            raise ArmnetNativeError(f"{name}: expected a contiguous int32 tensor on the HIP device")
-    check(load().armnet_shard_route_unique_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R),
-                                               ctypes.c_int64(nfeat), _ptr(counts), _ptr(send_local), _ptr(perm),
-                                               ctypes.c_void_p(0), _ptr(workspace),
-                                               ctypes.c_int64(workspace.numel() * workspace.element_size()),
-                                               _ptr(id_status), _stream()))
+    _ids_ok(ids)
+    _i32_ok(counts=counts, send_local=send_local, perm=perm)
+    with _on(ids, counts, send_local, perm, workspace, id_status):
+        check(load().armnet_shard_route_unique_ids(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R),
+                                                   ctypes.c_int64(nfeat), _ptr(counts), _ptr(send_local), _ptr(perm),
+                                                   ctypes.c_void_p(0), _ptr(workspace),
+                                                   ctypes.c_int64(workspace.numel() * workspace.element_size()),
+                                                   _ptr(id_status), _stream()))

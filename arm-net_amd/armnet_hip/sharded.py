@@ -26,8 +26,9 @@ class HipShardOps:
     def __init__(self):
         self._ws = None          # workspace of the de-duplicating route, reused across steps
 
-    def route(self, ids_flat, R, nfeat, dedup=False):
-        """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once."""
+    def route(self, ids_flat, R, nfeat, dedup=False, id_status=None):
+        """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once.
+        id_status (int32[1], optional) is OR-ed with 1 when an id lies outside [0, nfeat) (such ids read row 0)."""
         n = ids_flat.numel()
         dev = ids_flat.device
         counts = torch.empty(R, device=dev, dtype=torch.int32)
@@ -37,10 +38,10 @@ class HipShardOps:
             need = native.shard_route_unique_ws_bytes(R, nfeat)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                 self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
-            native.shard_route_unique_ids(n, ids_flat, R, nfeat, counts, send_local, perm, self._ws)
+            native.shard_route_unique_ids(n, ids_flat, R, nfeat, counts, send_local, perm, self._ws, id_status)
         else:
             ws = torch.empty(max(native.shard_route_ws_bytes(n, R), 4), device=dev, dtype=torch.uint8)
-            native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws)
+            native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws, id_status)
         return counts, send_local, perm
 
     def gather(self, local_idx, table_local):
@@ -74,8 +75,9 @@ class RowShardedTable:
         if table_local.shape[0] != expect:
             raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
 
-    def lookup(self, ids):
-        """ids [B, F] (this rank's samples) -> (rows [B*F, E] in send order, perm [B*F] int32)."""
+    def lookup(self, ids, id_status=None):
+        """ids [B, F] (this rank's samples) -> (rows [B*F, E] in send order, perm [B*F] int32).
+        id_status: optional int32[1] device flag, set when an id is out of range (the caller raises IndexError)."""
         R = self.world
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
@@ -85,7 +87,8 @@ class RowShardedTable:
             send_local = torch.empty(0, device=flat.device, dtype=torch.int32)
             perm = torch.empty(0, device=flat.device, dtype=torch.int32)
         else:
-            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
+            counts, send_local, perm = (self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
+                                        if id_status is not None else self.ops.route(flat, R, self.nfeat, dedup=dedup))
         E = self.table_local.shape[1]
         if R == 1 and not dist.is_initialized():
             n_send = int(counts.sum().item()) if dedup else n
@@ -118,19 +121,29 @@ class RowShardedTable:
 
 
 def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
-                      write_clamped_vals=True, flags=0, micro_batches=None):
+                      write_clamped_vals=True, flags=0, micro_batches=None, check_ids=False):
     """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E].
 
     With micro_batches > 1 the batch is processed in slices whose lookups (routing, the two exchanges, the owner-side
     gather) run on a side stream, so the exchange of slice m+1 overlaps the fused kernel of slice m.  Every rank must
-    use the same number of slices (the collectives pair up slice by slice).  Default: `shard.micro_batches` (1)."""
+    use the same number of slices (the collectives pair up slice by slice).  Default: `shard.micro_batches` (1).
+    With check_ids an out-of-range id raises IndexError like the replicated path (one host sync at the end of the call;
+    the routing kernels flag it, the lookup itself reads row 0 for such an id)."""
     from .block import arm_block_forward
     B, F = vals.shape
     M = int(micro_batches if micro_batches is not None else getattr(shard, "micro_batches", 1))
+    status = torch.zeros(1, device=ids.device, dtype=torch.int32) if (check_ids and ids.is_cuda) else None
+
+    def finish(out):
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("index out of range in self")
+        return out
+
     if M <= 1 or not vals.is_cuda:
-        rows, perm = shard.lookup(ids)
-        return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
-                                 n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags)
+        rows, perm = shard.lookup(ids, status)
+        return finish(arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
+                                        n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False,
+                                        flags=flags))
     O, E = q_fold.shape
     out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
     compute = torch.cuda.current_stream()
@@ -142,7 +155,7 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
     for m in range(M):
         lo, hi = m * step, min(B, (m + 1) * step)   # every rank runs M slices, possibly an empty last one
         with torch.cuda.stream(side):
-            rows, perm = shard.lookup(ids[lo:hi])
+            rows, perm = shard.lookup(ids[lo:hi], status)
             ready = side.record_event()
         if hi > lo:
             compute.wait_event(ready)
@@ -151,4 +164,4 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
             arm_block_forward(perm.view(hi - lo, F), vals[lo:hi], rows, q_fold, values, bn_scale, bn_shift, alpha,
                               n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags,
                               out=out[lo:hi])
-    return out
+    return finish(out)

@@ -23,6 +23,7 @@ template <typename IdT, int TPB>
 __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int F = a.F, E = a.E, O = a.O;
+    const int O_all = a.O_all ? a.O_all : O;          // neurons per sample in z / dz (this launch may be a slice)
     constexpr int CS = TPB + 1;                       // column stride (odd: conflict-free)
     float* xs = lds;                                  // [S][F][E]
     float* dss = xs + (((size_t)S * F * E + 3) & ~(size_t)3);      // [S][O][E]
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
                 pw[f * CS] = acc;
             }
             sparse_map_row(pw, CS, F, a.cfg);                         // p (same solver as the forward)
-            const size_t zo = ((size_t)(b0 + s) * O + o) * E;
+            const size_t zo = ((size_t)(b0 + s) * O_all + o) * E;
             const float cA = a.bn_a ? a.bn_a[o] : 1.0f, cB = a.bn_a ? a.bn_b[o] : 0.f, cC = a.bn_a ? a.bn_c[o] : 0.f;
             for (int e = 0; e < E; ++e) {
                 const float zv = a.z[zo + e];
@@ -161,11 +162,25 @@ int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
         const int rc = launch_fused_bwd_mfma(a, st);
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }
-    if (a.O <= 128)
-        return a.id_type == ARMNET_ID_I64 ? launch_bwd_t<int64_t, 128>(a, st) : launch_bwd_t<int32_t, 128>(a, st);
-    if (a.O <= 256)
-        return a.id_type == ARMNET_ID_I64 ? launch_bwd_t<int64_t, 256>(a, st) : launch_bwd_t<int32_t, 256>(a, st);
-    return ARMNET_ERR_UNSUPPORTED;
+    // slices of <= 256 neurons (a thread per neuron row): the table gradient is additive over the neurons, the
+    // parameter gradients and z / dz are addressed per slice — the forward accepts any neuron count, so must this
+    for (int o0 = 0; o0 < a.O; o0 += 256) {
+        BwdArgs s = a;
+        s.O = a.O - o0 < 256 ? a.O - o0 : 256;
+        s.O_all = a.O_all ? a.O_all : a.O;
+        s.q_fold = a.q_fold + (size_t)o0 * a.E;
+        s.values = a.values + (size_t)o0 * a.F;
+        s.z = a.z + (size_t)o0 * a.E;
+        s.dz = a.dz + (size_t)o0 * a.E;
+        if (a.bn_a) { s.bn_a = a.bn_a + o0; s.bn_b = a.bn_b + o0; s.bn_c = a.bn_c + o0; }
+        s.d_values = a.d_values + (size_t)o0 * a.F;
+        s.d_qfold = a.d_qfold + (size_t)o0 * a.E;
+        const int rc = s.O <= 128
+            ? (a.id_type == ARMNET_ID_I64 ? launch_bwd_t<int64_t, 128>(s, st) : launch_bwd_t<int32_t, 128>(s, st))
+            : (a.id_type == ARMNET_ID_I64 ? launch_bwd_t<int64_t, 256>(s, st) : launch_bwd_t<int32_t, 256>(s, st));
+        if (rc != ARMNET_OK) return rc;
+    }
+    return ARMNET_OK;
 }
 
 }  // namespace armnet
