@@ -62,6 +62,17 @@ def _stress(model, gen):
             w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
 
 
+def _wide(model, gen, vscale=8.0):
+    """'wide' weight regime (round-2 verdict 1c): embeddings ~ N(0,1), values x8 on top of the stress regime's
+    sharpened queries and live BatchNorm statistics, so that the exponent of the interaction (armnet_1h.py:86) spans
+    about +-10 and the neurons 1e-4 ... 1e4: the relative error of exp2(z * log2e / S) grows with |z|"""
+    _stress(model, gen)
+    with torch.no_grad():
+        w = model.embedding.embedding.weight
+        w.copy_(torch.randn(w.shape, generator=gen))
+        model.attn_layer.values.mul_(vscale)
+
+
 def _inputs(B, F, nfeat, gen):
     ids = torch.randint(0, nfeat, (B, F), generator=gen, dtype=torch.int64)
     vals = torch.rand(B, F, generator=gen)
@@ -119,7 +130,13 @@ def _capture(model, ids, vals, train=False):
     return cap
 
 
-def _save(name, meta, sd, ids, vals, cap):
+LEAN = ("vals_clamped", "p", "neurons", "x_arm", "logits")     # what the larger (B = 64) fixtures keep
+LEAN_MH = ("vals_clamped", "x_arm", "logits")                  # many-neuron cases: the block's output and the logits
+
+
+def _save(name, meta, sd, ids, vals, cap, keep=None):
+    if keep is not None:
+        cap = {k: v for k, v in cap.items() if k in keep or k.startswith("after/")}
     out = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
     out["in/ids"] = ids.numpy()
     out["in/vals"] = vals.numpy()
@@ -132,7 +149,7 @@ def _save(name, meta, sd, ids, vals, cap):
     print(f"{name:42s} {os.path.getsize(path) / 1024:8.1f} KiB  logits[:3]={cap['logits'].flatten()[:3].tolist()}")
 
 
-def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=False):
+def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=False, keep=None):
     """ctor: dict of constructor args in the reference's own names."""
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1000)
@@ -146,6 +163,8 @@ def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=
                   ctor["deep_nlayer"], ctor["deep_nhid"])
     if regime == "stress":
         _stress(m, gen)
+    elif regime.startswith("wide"):
+        _wide(m, gen, 8.0 * float(regime[4:] or 1))
     if ids is None:
         ids, vals = _inputs(B, ctor["nfield"], ctor["nfeat"], gen)
     sd_before = {k: v.clone() for k, v in m.state_dict().items()}
@@ -157,7 +176,10 @@ def model_case(name, variant, ctor, B, seed, regime, ids=None, vals=None, train=
         for k, v in m.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 cap["after/" + k] = v.clone()
-    _save(name, meta, sd_before, ids, vals, cap)
+    if regime.startswith("wide"):
+        z = cap["neurons"]
+        print(f"    neurons span {float(z.min()):.3e} ... {float(z.max()):.3e}, |x_arm| max {float(cap['x_arm'].abs().max()):.3e}")
+    _save(name, meta, sd_before, ids, vals, cap, keep=keep)
 
 
 def grad_case(name, variant, ctor, B, seed, train_mode):
@@ -290,6 +312,9 @@ def main():
     run_sh_cases()
     more_cases()
     run_sh_grad_cases()
+    b64_cases()
+    wide_cases()
+    big_batch_grad_cases()
 
 
 def run_sh_cases():
@@ -348,6 +373,41 @@ def alpha25_grad_cases():
     grad_case("h2_grad_criteo_1h_h32_e16_a2.5_evalbn", "1h", base(39, 200, 16, 2.5, 32, mlp_nhid=16), 16, 108, False)
 
 
+def b64_cases():
+    """G10 - SURVEY §8c's batch of 64 (nfeat 4096) for every BASELINE.json configuration, stress weights; only the
+    block's outputs and the logits are kept (LEAN) to bound the fixture size"""
+    for alpha in (1.0, 1.5, 1.7, 2.0, 2.5):
+        model_case(f"g10_criteo_1h_a{alpha}_b64", "1h", base(39, 4096, 16, alpha, 32, mlp_nhid=256 if alpha == 2.0 else 32),
+                   64, 121, "stress", keep=LEAN)
+    for alpha in (1.7, 2.0):
+        model_case(f"g10_criteo_mh4_a{alpha}_b64", "mh",
+                   base(39, 4096, 16, alpha, 32, nhead=4, mlp_nhid=256 if alpha == 2.0 else 32), 64, 122, "stress", keep=LEAN_MH)
+    model_case("g10_criteo_1h_e64_a1.7_b64", "1h", base(39, 1024, 64, 1.7, 32, mlp_nhid=32), 64, 123, "stress", keep=LEAN_MH)
+    model_case("g10_avazu_mh4_ens_a1.7_b64", "mh", base(22, 2048, 32, 1.7, 32, nhead=4, ensemble=True, mlp_nhid=32,
+                                                        deep_nhid=256), 64, 124, "stress", keep=LEAN_MH)
+    model_case("g10_frappe_1h_a1.7_b64", "1h", base(10, 5382, 10, 1.7, 10, mlp_nhid=64), 64, 125, "stress", keep=LEAN)
+
+
+def wide_cases():
+    """G11 - the wide-exponent regime (neurons spanning >= 1e-4 ... 1e4), B = 64"""
+    for alpha in (1.0, 1.5, 1.7, 2.0, 2.5):
+        model_case(f"g11_criteo_1h_a{alpha}_wide", "1h", base(39, 4096, 16, alpha, 32), 64, 131, "wide", keep=LEAN)
+    model_case("g11_criteo_mh4_a2.0_wide", "mh", base(39, 4096, 16, 2.0, 32, nhead=4), 64, 132, "wide4", keep=LEAN_MH)
+    model_case("g11_criteo_1h_e64_a1.7_wide", "1h", base(39, 1024, 64, 1.7, 32), 64, 133, "wide", keep=LEAN_MH)
+    model_case("g11_criteo_1h_h128_e10_a2.0_wide", "1h", base(39, 1024, 10, 2.0, 128, mlp_nhid=16), 64, 134, "wide", keep=LEAN_MH)
+
+
+def big_batch_grad_cases():
+    """H3 - gradients of a training step at B = 256 (train-mode BatchNorm over 256 x nemb values per channel: the
+    round-1 fixtures' 16-24-sample statistics amplified the block's 5e-7 agreement to 1e-2)"""
+    for alpha in (1.7, 2.0):
+        grad_case(f"h3_grad_1h_a{alpha}_train_b256", "1h", base(39, 256, 16, alpha, 32, mlp_nhid=16), 256, 141, True)
+    grad_case("h3_grad_mh2_a1.5_train_b256", "mh", base(13, 128, 8, 1.5, 8, nhead=2, mlp_nhid=16), 256, 142, True)
+    grad_case("h3_grad_1h_ens_a2.0_train_b256", "1h", base(22, 128, 32, 2.0, 32, ensemble=True, mlp_nhid=16, deep_nhid=16),
+              256, 143, True)
+    grad_case("h3_grad_1h_a1.0_train_b2304", "1h", base(10, 128, 10, 1.0, 16, mlp_nhid=16), 2304, 144, True)
+
+
 def entmax_grad_cases():
     """G6b: backward of the sparse map alone (utils/entmax.py:70-80), dX for a random dY."""
     from utils.entmax import entmax_bisect
@@ -372,7 +432,11 @@ def entmax_grad_cases():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2-only":      # add the round-2 cases without rewriting the others
+        b64_cases()
+        wide_cases()
+        big_batch_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
         entmax_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":
         run_sh_grad_cases()

@@ -1,0 +1,140 @@
+"""The code path bench.py times, under parity (round-1 verdict "What's weak" 1): the BASELINE.json configurations built
+exactly as bench.py builds them (same model factory, same batch generator), at batch sizes where every wave of the
+persistent grid takes SEVERAL groups — the software pipeline's steady state (rows of group k+1 and raw ids of group
+k+2 in flight), the clamp-past-the-end re-reads, the short last group and the 32-bit offset arithmetic at scale —
+against the CPU oracle, elementwise 1e-5, and bit-equal across the id sources (int64 / int32 / pre-gathered rows)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import armnet_oracle as orc
+from tol_util import TOL, assert_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bench_args(**kw):
+    d = dict(gpus=1, steps=1, warmup=0, alpha=2.0, regime="fresh", batch=65537, nfield=39, nfeat=1_000_000, nemb=16,
+             nhid=32, nhead=1, ids="uniform", shard="replicate", micro_batches=1, rotate=1)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _run_case(a, oracle_rows=None):
+    import bench
+    from armnet_hip.block import arm_block_forward
+    model = bench.build_model(a, torch.device(DEV), regime=a.regime)
+    ids, vals, ids_cpu, vals_cpu = bench.make_batch(a, 0, torch.device(DEV), 0)
+    with torch.no_grad():
+        v64 = vals.clone()
+        got = model.arm_block(ids, v64)
+        v32 = vals.clone()
+        got32 = model.arm_block(ids.to(torch.int32), v32)
+        f = model._folded
+        rows = model.embedding.embedding.weight[ids].contiguous()            # [B,F,E] unscaled
+        vr = vals.clone()
+        got_rows = arm_block_forward(None, vr, None, f.q_fold, model.attn_layer.values, f.bn_scale, f.bn_shift,
+                                     model.alpha, rows=rows)
+        del rows
+    assert torch.equal(got, got32), "int32 ids must be bit-equal to int64 ids"
+    assert torch.equal(got, got_rows), "pre-gathered rows must be bit-equal to the in-kernel gather"
+    assert torch.equal(v64, v32) and torch.equal(v64, vr)
+    n = a.batch if oracle_rows is None else min(a.batch, oracle_rows)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    orc.set_threads(orc.effective_cpus())
+    # the oracle sees the whole batch when it is affordable, else its head AND its tail (the short last group)
+    sel = np.arange(a.batch) if n == a.batch else np.r_[0:n // 2, a.batch - (n - n // 2):a.batch]
+    v = vals_cpu.numpy()[sel].copy()
+    want = orc.arm_block("1h" if a.nhead == 1 else "mh", ids_cpu.numpy()[sel], v, sd, float(a.alpha))
+    np.testing.assert_array_equal(v64.cpu().numpy()[sel], v)                # the in-place clamp
+    assert_close(got.cpu().numpy()[sel], want, TOL, f"alpha={a.alpha} {a.regime}")
+
+
+@pytest.mark.parametrize("alpha", [2.0, 1.7])
+@pytest.mark.parametrize("regime", ["fresh", "stress"])
+def test_headline_config_as_bench_builds_it(alpha, regime):
+    """BASELINE.json configs[1]: armnet_1h nfield=39 nfeat=1M nemb=16 nhid=32, B = 65 537 (> 8 192: every wave of the
+    persistent grid runs its pipeline's steady state; odd: the last group is short)"""
+    _run_case(_bench_args(alpha=alpha, regime=regime))
+
+
+@pytest.mark.parametrize("alpha,regime", [(2.0, "stress"), (1.7, "fresh")])
+def test_config3_multi_head_as_bench_builds_it(alpha, regime):
+    """BASELINE.json configs[2]: armnet nhead=4 x nhid=32 (128 neurons: 8 passes per group), B = 20 011"""
+    _run_case(_bench_args(alpha=alpha, regime=regime, nhead=4, batch=20011))
+
+
+@pytest.mark.parametrize("alpha,regime", [(2.0, "stress"), (1.7, "stress")])
+def test_config4_shape_nemb64_as_bench_builds_it(alpha, regime):
+    """BASELINE.json configs[3] shape on one GPU: nemb=64 (one sample per wave-group), nfeat 2M, B = 20 011"""
+    _run_case(_bench_args(alpha=alpha, regime=regime, nemb=64, nfeat=2_000_000, batch=20011))
+
+
+def test_config5_shape_avazu_as_bench_builds_it():
+    """BASELINE.json configs[4] block shape: nfield=22 nemb=32 nhead=4, B = 20 011"""
+    _run_case(_bench_args(alpha=1.7, regime="stress", nfield=22, nemb=32, nhead=4, nfeat=2_000_000, batch=20011))
+
+
+def test_headline_alpha25_literal_bisection():
+    """alpha = 2.5 (run.sh:11,37): the literal bisection mode at the headline shape; oracle on 16 384 of the 65 537"""
+    _run_case(_bench_args(alpha=2.5, regime="stress"), oracle_rows=16384)
+
+
+def test_bench_rotating_batches_are_distinct_and_reproducible():
+    import bench
+    a = _bench_args(batch=1024)
+    b0 = bench.make_batch(a, 0, torch.device(DEV), 0)
+    b0_again = bench.make_batch(a, 0, torch.device(DEV), 0)
+    b1 = bench.make_batch(a, 0, torch.device(DEV), 1)
+    assert torch.equal(b0[0], b0_again[0]) and torch.equal(b0[1], b0_again[1])
+    assert not torch.equal(b0[0], b1[0]) and not torch.equal(b0[1], b1[1])
+
+
+# the large-batch scan of tools/shape_scan_big.py, reduced: persistent-loop / pipeline paths of the matrix-core kernels
+# for every staging family against the shape-agnostic kernel, int32 ids, pre-gathered rows, value write-back
+BIG_SCAN = [(B, F, E, O, alpha)
+            for B in (20011, 65537)
+            for (F, E) in ((1, 5), (3, 10), (7, 16), (10, 10), (13, 20), (16, 64), (22, 32), (24, 5), (31, 16), (39, 10),
+                           (39, 16), (39, 64), (43, 10), (48, 20), (48, 32))
+            for (O, alpha) in (((7, 2.0), (24, 1.7)) if (F + E) % 2 else ((32, 1.5), (40, 1.0)))]
+
+
+@pytest.mark.parametrize("B,F,E,O,alpha", BIG_SCAN)
+def test_large_batch_scan_matrix_core_vs_generic(B, F, E, O, alpha):
+    from armnet_hip import native
+    nfeat = 5003
+    assert native.fused_kernel_kind(F, E, O, alpha) == 1
+    g = torch.Generator().manual_seed(F * 1000 + E * 10 + O)
+    table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
+    qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+    values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals0 = (torch.rand(B, F, generator=g) * 1.2 - 0.1).to(DEV)          # some outside [1e-3, 1]
+    sc, sh = (torch.rand(O, generator=g) + 0.5).to(DEV), torch.randn(O, generator=g).to(DEV)
+    outs = {}
+    for name, flags, idt in (("gen", native.F_FORCE_GENERIC | native.F_WRITE_CLAMPED_VALS, ids),
+                             ("mfma", native.F_WRITE_CLAMPED_VALS, ids),
+                             ("mfma32", native.F_WRITE_CLAMPED_VALS, ids.to(torch.int32))):
+        v = vals0.clone()
+        z = torch.empty(B, O, E, device=DEV)
+        native.fused_fwd(B, F, E, O, alpha, 50, flags, idt, v, table, qf, values, sc, sh, z)
+        outs[name] = (z, v)
+    rows = table[ids].contiguous()
+    v = vals0.clone()
+    z = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd_from_rows(B, F, E, O, alpha, 50, native.F_WRITE_CLAMPED_VALS, rows, v, qf, values, sc, sh, z)
+    outs["rows"] = (z, v)
+    zg, vg = outs["gen"]
+    assert torch.equal(outs["mfma"][0], outs["mfma32"][0]) and torch.equal(outs["mfma"][0], outs["rows"][0])
+    for k in ("mfma", "mfma32", "rows"):
+        assert torch.equal(outs[k][1], vg), f"{k}: clamped values differ"
+    assert_close(outs["mfma"][0].cpu().numpy(), zg.cpu().numpy(), TOL, f"B={B} F={F} E={E} O={O} alpha={alpha}")

@@ -29,9 +29,12 @@ def test_training_step_matches_reference_gradients(name):
     loss = torch.nn.BCEWithLogitsLoss()(logits, y)
     loss.backward()
     # train-mode BatchNorm over a 16..24-sample batch divides by small batch deviations: the 5e-7 agreement
-    # of the fused block is amplified ~50x on the logits (the oracle shows the same against the fixtures)
-    assert _close(logits.detach().cpu().numpy(), ref["logits"], 5e-4 if meta["train"] else 2e-5), "logits"
-    assert abs(float(loss.detach()) - float(ref["loss"])) <= (1e-4 if meta["train"] else 2e-6)
+    # of the fused block is amplified ~50x on the logits (the oracle shows the same against the fixtures);
+    # the h3_* fixtures (B >= 256) hold the tight bars
+    big = name.startswith("h3_")
+    small_train = meta["train"] and not big
+    assert _close(logits.detach().cpu().numpy(), ref["logits"], 5e-4 if small_train else 2e-5), "logits"
+    assert abs(float(loss.detach()) - float(ref["loss"])) <= (1e-4 if small_train else 2e-6)
     np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])
     worst = {}
     gmax = max(float(np.abs(ref["grad/" + k]).max()) for k, _ in m.named_parameters())
@@ -44,7 +47,7 @@ def test_training_step_matches_reference_gradients(name):
         worst[k] = err
     print(name, {k: f"{v:.1e}" for k, v in worst.items() if v > 1e-5})
     for k, err in worst.items():
-        assert err <= (1e-2 if meta["train"] else 2e-4), f"grad of {k}: rel err {err:.2e}"
+        assert err <= (1e-2 if small_train else 2e-4), f"grad of {k}: rel err {err:.2e}"
 
 
 def test_train_mode_updates_bn_running_stats_like_the_reference():
@@ -217,3 +220,54 @@ def test_entmax_backward_matches_reference_gradients():
         assert float((Y.detach().cpu() - torch.from_numpy(z["Y/" + k])).abs().max()) <= 2e-6, k
         ref = torch.from_numpy(z["dX/" + k])
         assert float((X.grad.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), k
+
+
+def test_splitk_linear_backward_matches_nn_linear_at_large_batch():
+    """_LinearSplitKFn is only taken at B >= 2048 (no reference-gradient fixture is that large): its gradients against
+    nn.Linear's on the same input, including a gradient that arrives as a non-contiguous view"""
+    from armnet_hip.modules import _LinearSplitKFn
+    g = torch.Generator().manual_seed(3)
+    B, K, N = 4096 + 2048, 96, 40                       # 6144 = 2^11 * 3: S stops at 4
+    x = torch.randn(B, K, generator=g).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    dy_t = torch.randn(N, B, generator=g).to(DEV).t()   # non-contiguous [B, N]
+    assert not dy_t.is_contiguous()
+    want = lin(x)
+    want.backward(dy_t)
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None
+    lin.zero_grad()
+    got = _LinearSplitKFn.apply(x, lin.weight, lin.bias)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    got.backward(dy_t)
+    torch.testing.assert_close(x.grad, gx, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lin.bias.grad, gb, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(lin.weight.grad, gw, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("F,E,O", [(50, 8, 300), (5, 2, 520)])
+def test_generic_backward_handles_more_than_256_neurons(F, E, O):
+    """shapes only the shape-agnostic kernels take (nfield > 48 / nemb < 4) with more neurons than one 256-thread
+    slice: forward succeeds, so the backward must too — against torch autograd of the composed ops (alpha = 1)"""
+    from armnet_hip import native
+    assert native.fused_kernel_kind(F, E, O, 1.0) == 0
+    g = torch.Generator().manual_seed(F + O)
+    B, nfeat = 19, 31
+    table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV).requires_grad_(True)
+    qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV).requires_grad_(True)
+    values = (torch.randn(O, F, generator=g) * 0.4).to(DEV).requires_grad_(True)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+    dz = torch.randn(B, O, E, generator=g).to(DEV)
+    x = table[ids] * vals.unsqueeze(2)                                   # layers.py:20-21
+    p = torch.softmax(torch.einsum("bfe,oe->bof", x, qf), dim=-1)        # folded gates, alpha = 1
+    z_ref = torch.exp(torch.einsum("bof,bfe->boe", p * values, x))       # armnet_1h.py:34,86
+    z_ref.backward(dz)
+    one, zero = torch.ones(O, device=DEV), torch.zeros(O, device=DEV)
+    z = torch.empty(B, O, E, device=DEV)
+    native.fused_fwd(B, F, E, O, 1.0, 50, 0, ids, vals, table.detach(), qf.detach(), values.detach(), one, zero, z)
+    torch.testing.assert_close(z, z_ref.detach(), rtol=1e-5, atol=1e-6)
+    dt, dv, dq = torch.zeros_like(table), torch.zeros_like(values), torch.zeros_like(qf)
+    native.fused_bwd(B, F, E, O, 1.0, 50, 0, ids, vals, table.detach(), qf.detach(), values.detach(), z, dz, dt, dv, dq)
+    for name, a, b in (("d_table", dt, table.grad), ("d_values", dv, values.grad), ("d_qfold", dq, qf.grad)):
+        assert float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) <= 2e-5, name

@@ -173,3 +173,29 @@ def test_roc_auc_matches_sklearn_including_ties():
         assert abs(roc_auc_compute_fn(p, y) - want) <= 1e-12
         assert abs(float(roc_auc_device(p.requires_grad_(True), y)) - want) <= 1e-12
     assert roc_auc_compute_fn(torch.randn(5), torch.ones(5)) == 0.      # one class only, like the reference helper
+
+
+def test_native_device_guard_rejects_cpu_and_empty_argument_lists():
+    """armnet_hip.native._on: every native call runs under the device of its tensor arguments (advisor finding r1);
+    host tensors or no tensors at all are refused before anything is launched"""
+    import torch
+    from armnet_hip import native
+    with pytest.raises(native.ArmnetNativeError):
+        native._on(torch.zeros(3))
+    with pytest.raises(native.ArmnetNativeError):
+        native._on(None, None)
+
+
+def test_fold_caches_can_be_invalidated_explicitly():
+    """writes through `.data` do not bump a parameter's version counter: invalidate_folded() (also called by
+    train()/eval()) drops the cached folds so the next eval call recomputes them"""
+    import torch
+    from models.armnet_1h import ARMNetModel
+    m = ARMNetModel(5, 20, 4, 1.7, 3, 4, 1, 8, 0.0, False, 1, 8)
+    m._folded.key = ("stale",)
+    m.mlp._fold_key = ("stale",)
+    m.invalidate_folded()
+    assert m._folded.key is None and m.mlp._fold_key is None
+    m._folded.key = ("stale",)
+    m.eval()
+    assert m._folded.key is None

@@ -7,6 +7,7 @@ import pytest
 
 from golden_util import load, load_entmax, model_cases
 from oracle import armnet_oracle as orc
+from tol_util import elem_excess
 
 STAGES = ["vals_clamped", "x_emb", "gates", "p", "arm_weight", "neurons", "x_arm", "logits"]
 # measured worst case over all fixtures is ~3e-7 (fp32 summation order inside ATen BLAS); bars below
@@ -19,10 +20,14 @@ def test_forward_matches_reference(name):
     meta, sd, ids, vals, ref = load(name)
     got = orc.forward(meta["variant"], meta["ctor"], sd, ids, vals, train=meta["train"])
     for k in STAGES:
+        if k not in ref:                       # the B = 64 fixtures keep the block's outputs only
+            continue
         assert got[k].shape == ref[k].shape, (k, got[k].shape, ref[k].shape)
         err = float(np.max(np.abs(got[k].astype(np.float64) - ref[k]))) if ref[k].size else 0.0
         bar = TOL[k] * max(1.0, float(np.max(np.abs(ref[k])))) if ref[k].size else 0.0
         assert err <= bar, f"{name}: stage {k} max abs err {err:.3e} > {bar:.3e}"
+        if k != "logits":                      # every element within 1e-5 of its own magnitude (wide-range tensors)
+            assert elem_excess(got[k], ref[k], 1e-5) <= 1.0, f"{name}: stage {k} elementwise"
     if meta["train"]:
         for k in ("arm_bn.running_mean", "arm_bn.running_var"):
             np.testing.assert_allclose(got["after/" + k], ref["after/" + k], rtol=1e-5, atol=1e-6)
@@ -35,7 +40,9 @@ def test_fused_block_entry_matches_reference(name):
     v = np.array(vals, dtype=np.float32, copy=True)
     out = orc.arm_block(meta["variant"], ids, v, sd, float(meta["ctor"]["alpha"]))
     np.testing.assert_array_equal(v, ref["vals_clamped"])        # in-place side effect
-    assert np.max(np.abs(out - ref["x_arm"].reshape(out.shape))) <= TOL["x_arm"]
+    want = ref["x_arm"].reshape(out.shape)
+    assert np.max(np.abs(out - want)) <= TOL["x_arm"] * max(1.0, float(np.max(np.abs(want))))
+    assert elem_excess(out, want, 1e-5) <= 1.0
 
 
 def test_entmax_alone_matches_reference():
@@ -87,4 +94,5 @@ def test_cpu_twins_of_the_abi_match_the_reference(name):
     assert status == 0
     want = ref["x_arm"].reshape(out.shape)
     assert float(np.max(np.abs(out - want))) <= 1e-5 * max(1.0, float(np.max(np.abs(want))))
+    assert elem_excess(out, want, 1e-5) <= 1.0
     np.testing.assert_array_equal(v, ref["vals_clamped"])
