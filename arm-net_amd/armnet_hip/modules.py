@@ -495,10 +495,13 @@ class _MLP(nn.Module):
     """reference: models/layers.py:68-88 (state_dict keys mlp.<i>.*).
 
     Training mode on the GPU: hipBLASLt Linear, then BatchNorm1d + ReLU fused into the HIP passes of
-    bn_kernels.hip (HipBatchNorm1d).  In eval mode on the GPU each (Linear, BatchNorm1d, ReLU,
-    Dropout) group collapses to ONE hipBLASLt GEMM with a bias+ReLU epilogue: the BN affine is folded into
-    the Linear's weight and bias (W' = W * s, b' = b * s + t with s = gamma / sqrt(var + eps),
-    t = beta - mean * s; refreshed when any source tensor's version counter moves)."""
+    bn_kernels.hip (HipBatchNorm1d).  Eval-mode inference on the GPU: the whole head is ONE hand-written kernel
+    (armnet_mlp_head_f32, csrc/mlp_head.hip: BatchNorm folded into the weights, W' = W * s, b' = b * s + t with
+    s = gamma / sqrt(var + eps), t = beta - mean * s; operands split into three bf16 slices, six cross products on the
+    bf16 matrix cores, fp32 accumulate; packed weights refreshed when any source tensor's version counter moves) for
+    heads with 1..n hidden layers of width <= 256 and one output — every head the reference builds.  Anything else
+    (no hidden layer, several outputs, wider layers, `hip_head = False`) takes one hipBLASLt GEMM per folded
+    (Linear, BatchNorm1d, ReLU, Dropout) group with a bias+ReLU epilogue."""
 
     def __init__(self, ninput, nlayers, nhid, dropout, noutput=1):
         super().__init__()
@@ -506,15 +509,77 @@ class _MLP(nn.Module):
         self._fold_key = None
         self._folded = None
         self.fold_eval = True
+        self.hip_head = True           # eval-mode inference through armnet_mlp_head_f32 where it has a kernel
+        self._dims = (ninput, nlayers, nhid, noutput)
+        self._pack_key = None
+        self._packed = None            # [(K0, n_hidden, has_final, blob)] one entry per launch
 
     def eval_path(self):
         """which code runs the eval-mode head (reported by bench.py)"""
+        if self.hip_head and self._hip_plan() is not None:
+            return ("armnet_mlp_head_f32: ONE HIP kernel, bf16x3-split operands on v_mfma_f32_32x32x16_bf16 "
+                    "(6 cross products, fp32 accumulate), hidden layers chained in registers")
         return "torch/hipBLASLt fp32 GEMMs, BatchNorm folded into the weights, bias+ReLU epilogue"
 
     def invalidate(self):
-        """forget the folded eval-mode weights (see ArmNetBase.invalidate_folded)"""
+        """forget the folded / packed eval-mode weights (see ArmNetBase.invalidate_folded)"""
         self._fold_key = None
         self._folded = None
+        self._pack_key = None
+        self._packed = None
+
+    def _hip_plan(self):
+        """launch plan of the HIP head: [(first hidden layer index, number of hidden layers fused, has_final)], or
+        None when there is no kernel for this head (no hidden layer, more than one output, hidden width > 256)"""
+        ninput, nlayers, nhid, noutput = self._dims
+        if nlayers < 1 or noutput != 1 or not native.mlp_head_supported(ninput, nhid, 1):
+            return None
+        plan, i = [], 0
+        while i < nlayers:
+            n = 2 if nlayers - i >= 2 else 1
+            plan.append((i, n, i + n == nlayers))
+            i += n
+        return plan
+
+    def _groups(self):
+        """[(Linear, BatchNorm1d)] of the hidden layers and the final Linear"""
+        mods = list(self.mlp)
+        hidden = [(mods[i], mods[i + 1]) for i in range(0, len(mods) - 1, 4)]
+        return hidden, mods[-1]
+
+    def _pack(self):
+        mods = list(self.mlp)
+        src = [p for m in mods for p in list(m.parameters()) + list(m.buffers())]
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if key != self._pack_key:
+            ninput, nlayers, nhid, _ = self._dims
+            hidden, last = self._groups()
+            dev = last.weight.device
+            packed = []
+            with torch.no_grad():
+                for first, n, has_final in self._hip_plan():
+                    K0 = ninput if first == 0 else nhid
+                    blob = torch.zeros(native.mlp_packed_bytes(K0, nhid, n), device=dev, dtype=torch.uint8)
+                    for slot in range(n):
+                        lin, bn = hidden[first + slot]
+                        native.mlp_pack_layer(K0, nhid, n, slot, lin.weight.detach().contiguous(), lin.bias.detach(),
+                                              (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                               float(bn.eps)), blob)
+                    if has_final:
+                        native.mlp_pack_layer(K0, nhid, n, 2, last.weight.detach().contiguous(), last.bias.detach(),
+                                              None, blob)
+                    packed.append((K0, n, has_final, blob))
+            self._packed, self._pack_key = packed, key
+        return self._packed
+
+    def _hip_forward(self, x):
+        nhid = self._dims[2]
+        B = x.shape[0]
+        for K0, n, has_final, blob in self._pack():
+            out = torch.empty((B,) if has_final else (B, nhid), device=x.device, dtype=torch.float32)
+            native.mlp_head(B, K0, nhid, n, has_final, x, blob, out)
+            x = out
+        return x.view(B, 1)
 
     def _fold(self):
         mods = list(self.mlp)
@@ -559,6 +624,8 @@ class _MLP(nn.Module):
             return x
         if self.training or torch.is_grad_enabled() or not x.is_cuda or not self.fold_eval:
             return self.mlp(x)                   # autograd in eval mode / CPU: the plain nn.Sequential
+        if self.hip_head and x.dim() == 2 and x.dtype == torch.float32 and self._hip_plan() is not None:
+            return self._hip_forward(x if x.stride(1) == 1 else x.contiguous())
         for wt, b, relu in self._fold():
             x = torch._addmm_activation(b, x, wt) if relu else torch.addmm(b, x, wt)
         return x

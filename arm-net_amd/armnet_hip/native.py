@@ -28,7 +28,8 @@ EXPORTS = (
     "armnet_fused_bwd_f32", "armnet_shard_route_unique_ws_bytes", "armnet_shard_route_unique_ids",
     "armnet_fused_kernel_kind", "armnet_fused_bwd_bn_f32", "armnet_bn_stats_f32", "armnet_bn_finalize_f32",
     "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
-    "armnet_scatter_add_f32",
+    "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
+    "armnet_mlp_head_f32",
 )
 
 _lib = None
@@ -63,6 +64,7 @@ def load():
     lib.armnet_shard_route_ws_bytes.restype = ctypes.c_int64
     lib.armnet_shard_route_unique_ws_bytes.restype = ctypes.c_int64
     lib.armnet_last_hip_error.restype = ctypes.c_char_p
+    lib.armnet_mlp_packed_bytes.restype = ctypes.c_int64
     if lib.armnet_abi_version() != ABI_VERSION:
         raise ArmnetNativeError(f"ABI version mismatch: library {lib.armnet_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -330,3 +332,35 @@ def shard_route_unique_ids(n, ids, R, nfeat, counts, send_local, perm, workspace
                                                    ctypes.c_void_p(0), _ptr(workspace),
                                                    ctypes.c_int64(workspace.numel() * workspace.element_size()),
                                                    _ptr(id_status), _stream()))
+
+
+def mlp_head_supported(K0, nhid, n_hidden):
+    return bool(load().armnet_mlp_head_supported(int(K0), int(nhid), int(n_hidden)))
+
+
+def mlp_packed_bytes(K0, nhid, n_hidden):
+    n = int(load().armnet_mlp_packed_bytes(int(K0), int(nhid), int(n_hidden)))
+    if n < 0:
+        raise ArmnetNativeError(f"no MLP-head kernel for input width {K0}, hidden width {nhid}, {n_hidden} hidden layers")
+    return n
+
+
+def mlp_pack_layer(K0, nhid, n_hidden, slot, W, b, bn, packed):
+    """bn: None or (weight, bias, running_mean, running_var, eps)"""
+    _dev_f32(W, "W")
+    ts = [W, b, packed] + (list(bn[:4]) if bn is not None else [])
+    with _on(*ts):
+        bw, bb, bm, bv = (bn[0], bn[1], bn[2], bn[3]) if bn is not None else (None, None, None, None)
+        check(load().armnet_mlp_pack_layer_f32(int(K0), int(nhid), int(n_hidden), int(slot), _ptr(W), int(W.shape[1]),
+                                               _ptr(b), _ptr(bw), _ptr(bb), _ptr(bm), _ptr(bv),
+                                               ctypes.c_float(bn[4] if bn is not None else 0.0), _ptr(packed),
+                                               _stream()))
+
+
+def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
+    _dev_f32(out, "out")
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ArmnetNativeError("x: expected a float32 [B, K0] tensor with unit inner stride on the HIP device")
+    with _on(x, packed, out):
+        check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(bool(has_final)),
+                                         _ptr(x), ctypes.c_int64(x.stride(0)), _ptr(packed), _ptr(out), _stream()))

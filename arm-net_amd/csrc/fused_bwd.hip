@@ -163,10 +163,16 @@ int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }
     // slices of <= 256 neurons (a thread per neuron row): the table gradient is additive over the neurons, the
-    // parameter gradients and z / dz are addressed per slice — the forward accepts any neuron count, so must this
-    for (int o0 = 0; o0 < a.O; o0 += 256) {
+    // parameter gradients and z / dz are addressed per slice — the forward accepts any neuron count, so must this.
+    // Wide rows (nfield > 48) need the per-thread gate columns of 256 threads to fit LDS: else slices of 128.
+    auto lds_need = [&](int tpb, int o) {
+        return ((((size_t)a.F * a.E + 3) & ~(size_t)3) + (((size_t)o * a.E + 3) & ~(size_t)3) +
+                2 * (size_t)a.F * (tpb + 1) + (size_t)o * a.F + (size_t)o * a.E + 2 * (size_t)a.F) * sizeof(float);
+    };
+    const int slice = (a.O > 128 && lds_need(256, a.O < 256 ? a.O : 256) <= 150 * 1024) ? 256 : 128;
+    for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
-        s.O = a.O - o0 < 256 ? a.O - o0 : 256;
+        s.O = a.O - o0 < slice ? a.O - o0 : slice;
         s.O_all = a.O_all ? a.O_all : a.O;
         s.q_fold = a.q_fold + (size_t)o0 * a.E;
         s.values = a.values + (size_t)o0 * a.F;

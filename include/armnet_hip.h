@@ -229,6 +229,32 @@ int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R
                                   int32_t* counts, int32_t* send_local, int32_t* perm, int32_t* n_unique,
                                   void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
 
+/*
+ * The eval-mode prediction head — models/layers.py:68-88 `MLP`: n x (Linear, BatchNorm1d, ReLU, Dropout) then
+ * Linear(., 1) — as built by models/armnet_1h.py:67 / models/armnet.py:69 (and the ensemble's deep_mlp,
+ * armnet.py:96-97), on the bf16 matrix cores with fp32-equivalent numerics: activations and BatchNorm-folded
+ * weights are split into three bf16 slices each and the six significant cross products are accumulated in fp32
+ * (csrc/mlp_head.hip).  One launch fuses up to two hidden layers and, optionally, the final Linear; deeper heads
+ * chain launches through the hidden-activation output.  Eval mode only (running statistics, Dropout = identity).
+ *
+ *   armnet_mlp_head_supported   1 when (K0 = input width, nhid = hidden width <= 256, n_hidden = 1|2) has a kernel
+ *   armnet_mlp_packed_bytes     size of the packed-parameter blob of one launch (device memory, caller-allocated)
+ *   armnet_mlp_pack_layer_f32   parameter-only precompute (re-run when weights change), one call per layer:
+ *       slot 0: first hidden layer  W [nhid, K0],  slot 1: second hidden layer W [nhid, nhid],
+ *       slot 2: final Linear W [1, nhid], b [1].   bn_* = the BatchNorm1d behind the Linear (NULL: none):
+ *       W' = W * s, b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps); W' is then split into bf16
+ *       hi/mid/lo (round-to-nearest) in the kernel's operand order.
+ *   armnet_mlp_head_f32         x [B, K0] (row stride ldx floats) -> has_final ? out [B] (the logits, layers.py:88)
+ *                                                                              : out [B, nhid] (post-ReLU activations)
+ */
+int armnet_mlp_head_supported(int K0, int nhid, int n_hidden);
+int64_t armnet_mlp_packed_bytes(int K0, int nhid, int n_hidden);
+int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const float* W, int Kin, const float* b,
+                              const float* bn_weight, const float* bn_bias, const float* bn_running_mean,
+                              const float* bn_running_var, float bn_eps, void* packed, void* stream);
+int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final, const float* x, int64_t ldx,
+                        const void* packed, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

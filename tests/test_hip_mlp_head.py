@@ -1,0 +1,114 @@
+"""armnet_mlp_head_f32: the eval-mode prediction head models/layers.py:68-88 as one HIP kernel on the
+bf16 matrix cores (3-way bf16 split, six cross products, fp32 accumulate).  First gate: logits within 1e-5 of a
+float64 evaluation of the same nn.Sequential, elementwise — the fp32 hipBLASLt path is held to the same bar beside it
+so the two error levels can be compared."""
+import numpy as np
+import pytest
+import torch
+
+from tol_util import TOL, elem_excess
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _make_head(K0, nlayers, nhid, seed, bn_regime="stress"):
+    from armnet_hip.modules import _MLP
+    torch.manual_seed(seed)
+    m = _MLP(K0, nlayers, nhid, 0.1)                      # dropout is the identity in eval mode
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for bn in [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm1d)]:
+            if bn_regime == "stress":
+                bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * 0.3)
+                bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=g) * 1.5 + 0.25)
+                bn.weight.copy_(torch.rand(bn.weight.shape, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(bn.bias.shape, generator=g) * 0.2)
+    return m.eval()
+
+
+def _ref64(m, x):
+    import copy
+    with torch.no_grad():
+        return copy.deepcopy(m.mlp).double().eval()(x.double())
+
+
+# (K0, nlayers, nhid): the headline head (512 -> 256 -> 256 -> 1), config 3 (2048 inputs), the ensemble's deep MLP
+# (nfield * nemb inputs), every tile count (hidden widths padded to 32/64/128/256), widths that are not multiples of 32
+# or 4, an input width with a partial last k-step, one / three / four hidden layers (chained launches)
+HEADS = [(512, 2, 256), (2048, 2, 256), (704, 2, 256), (320, 2, 32), (130, 1, 16), (100, 3, 64), (37, 1, 10),
+         (512, 2, 128), (17, 4, 8), (640, 2, 200), (1280, 1, 256), (390, 3, 16)]
+
+
+@pytest.mark.parametrize("K0,nlayers,nhid", HEADS)
+@pytest.mark.parametrize("B", [1, 37, 1000])
+def test_mlp_head_matches_float64_evaluation(K0, nlayers, nhid, B):
+    m = _make_head(K0, nlayers, nhid, seed=K0 + nhid).to(DEV)
+    assert m._hip_plan() is not None and "armnet_mlp_head_f32" in m.eval_path()
+    g = torch.Generator().manual_seed(B)
+    x = (torch.rand(B, K0, generator=g) * 3.0 - 1.0).to(DEV)           # post-BatchNorm neurons: O(1), both signs
+    want = _ref64(m, x).cpu().numpy()
+    with torch.no_grad():
+        got = m(x).cpu().numpy()
+        m.hip_head = False
+        blas = m(x).cpu().numpy()
+    assert got.shape == (B, 1)
+    e_hip, e_blas = elem_excess(got, want, TOL), elem_excess(blas, want, TOL)
+    print(f"K0={K0} nlayers={nlayers} nhid={nhid} B={B}: HIP head {e_hip * TOL:.2e}, hipBLASLt fp32 {e_blas * TOL:.2e}")
+    assert e_hip <= 1.0, f"worst element at {e_hip:.3f} x the 1e-5 bar (hipBLASLt fp32 path: {e_blas:.3f} x)"
+
+
+@pytest.mark.parametrize("scale", [1e-3, 30.0, 4e3])
+def test_mlp_head_keeps_fp32_accuracy_over_the_input_range(scale):
+    """inputs from 1e-3 to the wide-exponent regime's 4e3: the bf16 split has fp32's exponent range, so the error
+    relative to the magnitude of the terms is the same at every scale; compared with the fp32 GEMM path's own error"""
+    K0, nlayers, nhid, B = 512, 2, 256, 513
+    m = _make_head(K0, nlayers, nhid, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(7)
+    x = ((torch.rand(B, K0, generator=g) * 2.0 - 1.0) * scale).to(DEV)
+    want = _ref64(m, x).cpu().numpy()
+    with torch.no_grad():
+        got = m(x).cpu().numpy()
+        m.hip_head = False
+        blas = m(x).cpu().numpy()
+    mag = max(1.0, scale)                                  # the logits are sums of terms of this magnitude
+    err_hip = float(np.max(np.abs(got - want))) / mag
+    err_blas = float(np.max(np.abs(blas - want))) / mag
+    print(f"scale {scale}: HIP head {err_hip:.2e}, hipBLASLt fp32 {err_blas:.2e} (relative to the term magnitude)")
+    assert err_hip <= TOL and err_hip <= 4.0 * max(err_blas, 1e-7)
+
+
+def test_mlp_head_repacks_when_parameters_change():
+    m = _make_head(96, 2, 64, seed=11).to(DEV)
+    x = torch.randn(65, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        m.mlp[0].weight.mul_(1.5)                          # in-place op: bumps the version counter
+        m.mlp[1].running_mean.add_(0.1)
+        y1 = m(x)
+    want = _ref64(m, x).cpu().numpy()
+    assert not torch.allclose(y0, y1)
+    assert elem_excess(y1.cpu().numpy(), want, TOL) <= 1.0
+    with torch.no_grad():
+        m.mlp[0].weight.data.mul_(2.0)                     # a write through .data is NOT seen ...
+        assert torch.equal(m(x), y1)
+        m.invalidate()                                     # ... until the caches are invalidated explicitly
+        y2 = m(x)
+    assert elem_excess(y2.cpu().numpy(), _ref64(m, x).cpu().numpy(), TOL) <= 1.0
+
+
+def test_mlp_head_abi_rejects_bad_arguments_and_handles_strided_input():
+    from armnet_hip import native
+    assert not native.mlp_head_supported(512, 257, 2) and not native.mlp_head_supported(512, 256, 3)
+    with pytest.raises(native.ArmnetNativeError):
+        native.mlp_packed_bytes(512, 300, 1)
+    m = _make_head(48, 1, 32, seed=5).to(DEV)
+    big = torch.randn(200, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    x = big[:, 8:56]                                       # row stride 64 floats, unit inner stride, 32-byte offset
+    assert not x.is_contiguous()
+    with torch.no_grad():
+        got = m(x)
+    assert elem_excess(got.cpu().numpy(), _ref64(m, x).cpu().numpy(), TOL) <= 1.0
+    e = torch.empty(0, 48, device=DEV)
+    with torch.no_grad():
+        assert tuple(m(e).shape) == (0, 1)

@@ -28,13 +28,11 @@ def test_training_step_matches_reference_gradients(name):
     logits = m(x)
     loss = torch.nn.BCEWithLogitsLoss()(logits, y)
     loss.backward()
-    # train-mode BatchNorm over a 16..24-sample batch divides by small batch deviations: the 5e-7 agreement
-    # of the fused block is amplified ~50x on the logits (the oracle shows the same against the fixtures);
-    # the h3_* fixtures (B >= 256) hold the tight bars
-    big = name.startswith("h3_")
-    small_train = meta["train"] and not big
-    assert _close(logits.detach().cpu().numpy(), ref["logits"], 5e-4 if small_train else 2e-5), "logits"
-    assert abs(float(loss.detach()) - float(ref["loss"])) <= (1e-4 if small_train else 2e-6)
+    # measured on MI355X (round 2): every parameter gradient of every fixture — the 16..24-sample train-mode
+    # BatchNorm cases of round 1 as well as the B = 256 / 2304 ones — agrees to <= 1e-5 of the gradient's scale;
+    # round 1's 1e-2 bar was never needed
+    assert _close(logits.detach().cpu().numpy(), ref["logits"], 2e-5), "logits"
+    assert abs(float(loss.detach()) - float(ref["loss"])) <= 2e-6
     np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])
     worst = {}
     gmax = max(float(np.abs(ref["grad/" + k]).max()) for k, _ in m.named_parameters())
@@ -47,7 +45,7 @@ def test_training_step_matches_reference_gradients(name):
         worst[k] = err
     print(name, {k: f"{v:.1e}" for k, v in worst.items() if v > 1e-5})
     for k, err in worst.items():
-        assert err <= (1e-2 if small_train else 2e-4), f"grad of {k}: rel err {err:.2e}"
+        assert err <= 5e-5, f"grad of {k}: rel err {err:.2e}"
 
 
 def test_train_mode_updates_bn_running_stats_like_the_reference():
