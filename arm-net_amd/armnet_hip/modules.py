@@ -576,7 +576,14 @@ class _MLP(nn.Module):
         nhid = self._dims[2]
         B = x.shape[0]
         for K0, n, has_final, blob in self._pack():
-            out = torch.empty((B,) if has_final else (B, nhid), device=x.device, dtype=torch.float32)
+            KP = (K0 + 15) // 16 * 16
+            if x.shape[1] < KP and (x.stride(0) < KP or B == 1):
+                # the kernel reads whole 16-float k-steps: pad odd widths with zeros (heads whose input width is a
+                # multiple of 16 — every BASELINE.json configuration — take the activations as they are)
+                x = torch.nn.functional.pad(x, (0, KP - x.shape[1]))
+            NP = (nhid + 15) // 16 * 16
+            out = (torch.empty(B, device=x.device, dtype=torch.float32) if has_final
+                   else torch.zeros(B, NP, device=x.device, dtype=torch.float32))   # pad columns stay zero
             native.mlp_head(B, K0, nhid, n, has_final, x, blob, out)
             x = out
         return x.view(B, 1)

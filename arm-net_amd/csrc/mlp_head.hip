@@ -19,9 +19,12 @@
 // choose, so k-step 2t+u of the next layer takes registers 8u..8u+7 of tile t and the packed weights are permuted to
 // match: hidden activations never leave the registers between layers, no transpose, no LDS round trip.
 //
-// One wave owns 32 samples through all layers; a 256-thread block = 4 waves = 128 samples.  The packed weights are one
-// linear stream of 1-KiB lane-ready blocks in consumption order; the block's waves pull it stage by stage
-// (one k-step of all its tiles) through a 2-deep LDS ring with global_load_lds_dwordx4, one barrier per stage.
+// One wave owns 32 samples through all layers; a 512-thread block = 8 waves = 256 samples, one block per CU.  The packed
+// weights are one linear stream of 1-KiB lane-ready blocks in consumption order; the block's waves pull it stage by stage
+// (one k-step of all its tiles) through a 3-deep LDS ring with global_load_lds_dwordx4, one barrier per stage; each
+// wave's activations come through its own 3-deep LDS ring the same way.
+#include <stdlib.h>
+
 #include "armnet_common.h"
 
 namespace armnet {
@@ -35,7 +38,7 @@ typedef f32x4m f32x4mu __attribute__((aligned(4)));   // gfx950: unaligned-mode 
 // layer >= 2 runs in groups of TG output tiles (the previous layer's 16*NT accumulator registers stay live as its B
 // operands, so only TG*16 more can be spent on accumulators); a stage of its weight stream covers KPS k-steps
 __host__ __device__ constexpr int mlp_tg(int NT) { return NT >= 8 ? 2 : (NT < 4 ? NT : 4); }
-__host__ __device__ constexpr int mlp_kps(int NT) { return NT >= 8 ? 2 : 1; }
+__host__ __device__ constexpr int mlp_kps(int NT) { return NT >= 8 ? 4 : 1; }
 
 struct MlpLayout {
     int NT, TG, NG, KPS, KS1, NS2;    // NS2: stages per group of layer 2
@@ -145,10 +148,11 @@ __global__ void mlp_pack_kernel(PackArgs p) {
 struct MlpArgs {
     int64_t B;
     int K0, n_hidden, has_final, N;
-    int64_t ldx;
+    int64_t ldx, ldo;      // row strides (floats) of x and of the hidden-activation output
     const float* x;
     const uint8_t* packed;
     float* out;
+    int dbg;      // developer ablation switches (ARMNET_DEV_FLAGS builds only; 0 in product builds)
 };
 
 // 8 fp32 -> three packed bf16x8 planes; h + m + l == x exactly (truncating 8-bit slices of the significand)
@@ -174,112 +178,255 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// the six significant cross products of one k-step for NTL tiles; tiles interleaved so that consecutive MFMAs never
-// wait on the same accumulator
-template <int NTL>
-__device__ __forceinline__ void step_mfma(f32x16* acc, const u32x4* st, int lane, u32x4 bh, u32x4 bm, u32x4 bl) {
-    constexpr int PAIR = NTL >= 2 ? 2 : 1;
-#pragma unroll
-    for (int t = 0; t < NTL; t += PAIR) {
-        u32x4 ah[PAIR], am[PAIR], al[PAIR];
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) {
-            ah[u] = st[((t + u) * 3 + 0) * 64 + lane];
-            am[u] = st[((t + u) * 3 + 1) * 64 + lane];
-            al[u] = st[((t + u) * 3 + 2) * 64 + lane];
-        }
-        // small terms first, the leading product last
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(al[u], bh, acc[t + u]);
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(ah[u], bl, acc[t + u]);
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(am[u], bm, acc[t + u]);
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(am[u], bh, acc[t + u]);
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(ah[u], bm, acc[t + u]);
-#pragma unroll
-        for (int u = 0; u < PAIR; ++u) acc[t + u] = mfma_bf16(ah[u], bh, acc[t + u]);
-    }
+// A operands (three bf16 planes) of a pair of output tiles
+template <int PAIR>
+struct APlanes { u32x4 h[PAIR], m[PAIR], l[PAIR]; };
+
+// ---- LDS reads by hand ------------------------------------------------------------------------------------------
+// While an LDS-DMA (global_load_lds) is in flight hipcc's wait-count pass treats the LGKM counter as unordered ("pending
+// flat": the DMA carries an LDS memory operand) and turns EVERY wait for a ds_read result into lgkmcnt(0) — a full drain
+// that also waits for the reads issued one instruction earlier (measured: four exposed LDS round trips per k-step,
+// a lone wave at 45 % of the matrix-core rate).  LDS returns in order, so the weight planes and activation tiles are
+// read with inline-asm ds_read_b128 and waited for with exact counts; each wait names the registers it makes valid
+// ("+v"), which orders their consumers behind it.
+__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+template <int N, int PAIR>
+__device__ __forceinline__ void lds_wait(u32x4 (&r)[PAIR]) {     // at most N younger LDS reads still outstanding
+    if constexpr (PAIR == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r[0]) : "n"(N) : "memory");
 }
 
+template <int PAIR>
+__device__ __forceinline__ void load_planes(APlanes<PAIR>& A, uint32_t blk, int t0) {   // blk: LDS byte address + lane*16
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) A.l[u] = lds_read16(blk + ((t0 + u) * 3 + 2) * 1024);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) A.m[u] = lds_read16(blk + ((t0 + u) * 3 + 1) * 1024);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) A.h[u] = lds_read16(blk + ((t0 + u) * 3 + 0) * 1024);
+}
+
+// One (k-step, tile pair) unit: the six significant cross products for PAIR tiles, smallest terms first
+//      l*bh | m*bm  m*bh | h*bl  h*bm  h*bh
+// with ONE set of A registers that rolls over to the next unit: a plane's registers are reloaded from LDS (`nxt`: LDS
+// byte address + lane*16 of the next unit's k-step block; t0n its first tile) as soon as its last product has been
+// issued, so the next unit's l / m / h planes have 5 / 4 / 3 MFMA slots (64 cycles each) to arrive.  At every wait
+// exactly the 2*PAIR reads issued after the awaited plane may still be in flight (fewer at the end of a stage).  The
+// PAIR accumulators alternate so that consecutive MFMAs never wait on each other.  sched_barrier(VALU) keeps MFMAs and
+// LDS traffic in this order and lets the VALU work (the bf16 split of the next k-step) float into the MFMA shadows.
+template <int PAIR, bool NEXT>
+__device__ __forceinline__ void unit(f32x16* acc, APlanes<PAIR>& A, u32x4 bh, u32x4 bm, u32x4 bl, uint32_t nxt, int t0n) {
+    constexpr int W = 2 * PAIR;
+    lds_wait<W, PAIR>(A.l);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.l[u], bh, acc[u]);
+    __builtin_amdgcn_sched_barrier(0x2);
+    if (NEXT) {
+#pragma unroll
+        for (int u = 0; u < PAIR; ++u) A.l[u] = lds_read16(nxt + ((t0n + u) * 3 + 2) * 1024);
+    }
+    lds_wait<NEXT ? W : PAIR, PAIR>(A.m);
+    __builtin_amdgcn_sched_barrier(0x2);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.m[u], bm, acc[u]);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.m[u], bh, acc[u]);
+    __builtin_amdgcn_sched_barrier(0x2);
+    if (NEXT) {
+#pragma unroll
+        for (int u = 0; u < PAIR; ++u) A.m[u] = lds_read16(nxt + ((t0n + u) * 3 + 1) * 1024);
+    }
+    lds_wait<NEXT ? W : 0, PAIR>(A.h);
+    __builtin_amdgcn_sched_barrier(0x2);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.h[u], bl, acc[u]);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.h[u], bm, acc[u]);
+#pragma unroll
+    for (int u = 0; u < PAIR; ++u) acc[u] = mfma_bf16(A.h[u], bh, acc[u]);
+    __builtin_amdgcn_sched_barrier(0x2);
+    if (NEXT) {
+#pragma unroll
+        for (int u = 0; u < PAIR; ++u) A.h[u] = lds_read16(nxt + ((t0n + u) * 3 + 0) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0x2);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// raw barrier: __syncthreads() would drain every LDS-DMA in flight (it fences with vmcnt(0))
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+constexpr int kWaves = 8;                 // waves per block: 256 samples share one pass of the weight stream
+constexpr int kWRing = 3;                 // weight stages resident in LDS (consumed | landing | requested)
+constexpr int kXRing = 3;                 // activation tiles per wave in LDS (read | landing | requested)
+
+#ifdef ARMNET_DEV_FLAGS
+// developer build: per-phase s_memtime sums over all waves (layer-1 stages): wait | barrier | first reads | units
+__device__ unsigned long long g_mlp_phase[8];
+#define MLP_PHASE(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - pt; pt = _n; } while (0)
+#else
+#define MLP_PHASE(i) do {} while (0)
+#endif
+
 template <int NT>
-__global__ void __launch_bounds__(256, 2) mlp_head_kernel(MlpArgs a) {
+__global__ void __launch_bounds__(64 * kWaves, 2) mlp_head_kernel(MlpArgs a) {
     constexpr int TG = mlp_tg(NT), NG = NT / TG, KPS = mlp_kps(NT), NS2 = 2 * NT / KPS;
     constexpr int ST1 = NT * 3 * 1024, ST2 = KPS * TG * 3 * 1024;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // [2][ST1] ring | tables
-    float* tabs = reinterpret_cast<float*>(lds + 2 * ST1);              // bias1 | bias2 | wlast | blast
+    static_assert(ST2 <= ST1, "a layer-2 stage must fit a ring slot");
+    constexpr int PAIR = NT >= 2 ? 2 : 1;
+    constexpr int NP1 = NT / PAIR;          // tile pairs per k-step, layer 1
+    constexpr int NP2 = TG / PAIR;          // tile pairs per k-step, layer 2 (one group)
+    constexpr int TAB_BYTES = ((3 * NT * 32 + 4) * 4 + 15) & ~15;
+    // LDS-DMA instructions per wave and stage (1 KiB each); every wave issues the same number so that the wait counts
+    // below are uniform (surplus instructions re-fetch an earlier block of the same stage: same bytes, same place)
+    constexpr int NW = (NT * 3 + kWaves - 1) / kWaves;
+    static_assert(KPS * TG == NT, "both layers' stages hold NT*3 blocks");
+    // LDS: [kWRing][ST1] weight ring | fp32 tables | [kWaves][kXRing][2 KiB] activation tiles
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float* tabs = reinterpret_cast<float*>(lds + kWRing * ST1);         // bias1 | bias2 | wlast | blast
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, hf = lane >> 5;
+    uint8_t* xring = lds + kWRing * ST1 + TAB_BYTES + wave * (kXRing * 2048);
+    // 32-bit LDS byte addresses for the hand-written ds_reads
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t ring_a = lds0 + lane * 16;                                   // + slot * ST1: lane-ready plane blocks
+    const uint32_t xring_a = lds0 + kWRing * ST1 + TAB_BYTES + wave * (kXRing * 2048);
     const MlpLayout L = mlp_layout(a.K0, NT, a.n_hidden);
     const int KS1 = L.KS1;
     const int Q = KS1 + (a.n_hidden >= 2 ? NG * NS2 : 0);              // stages of the whole stream
+#ifdef ARMNET_DEV_FLAGS
+    const bool dbg_nosync = a.dbg & 1, dbg_nox = a.dbg & 2, dbg_noglds = a.dbg & 4;
+#else
+    constexpr bool dbg_nosync = false, dbg_nox = false, dbg_noglds = false;
+#endif
 
-    // stage q of the stream -> ring slot q & 1 (1-KiB lane-linear blocks, round-robin over the 4 waves)
-    auto issue = [&](int q) {
-        const bool l1 = q < KS1;
-        const uint8_t* src = a.packed + (l1 ? (int64_t)q * ST1 : L.l2_off + (int64_t)(q - KS1) * ST2);
-        const int nblk = l1 ? NT * 3 : KPS * TG * 3;
-        uint8_t* dst = lds + (q & 1) * ST1;
-        for (int blk = wave; blk < nblk; blk += 4)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + blk * 1024 + lane * 16),
-                (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
-    };
-    int q = 0;
-    // make stage q consumable (its loads were issued one stage ago), then start stage q+1 into the slot every wave
-    // has finished reading
-    auto advance = [&]() -> const u32x4* {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (q + 1 < Q) issue(q + 1);
-        const u32x4* st = reinterpret_cast<const u32x4*>(lds + (q & 1) * ST1);
-        ++q;
-        return st;
-    };
-
-    issue(0);
-    {   // tables -> LDS
-        const float* src = reinterpret_cast<const float*>(a.packed + L.tab_off);
-        for (int i = threadIdx.x; i < 3 * NT * 32 + 4; i += 256) tabs[i] = src[i];
-    }
-    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + m;
-    const int64_t rowc = row < a.B ? row : a.B - 1;
-    const float* xr = a.x + rowc * a.ldx + 8 * hf;
-    const bool k_tail = (a.K0 & 15) != 0;
-
-    auto load_x = [&](int s, float (&v)[8]) {
-        if (!k_tail || s + 1 < KS1) {
-            const f32x4m lo = *reinterpret_cast<const f32x4mu*>(xr + 16 * s);
-            const f32x4m hi = *reinterpret_cast<const f32x4mu*>(xr + 16 * s + 4);
+    // stage q of the weight stream -> ring slot q % kWRing: NT*3 lane-linear 1-KiB blocks, NW per wave
+    auto issue_w = [&](int q) {
+        if (dbg_noglds) return;
+        const uint8_t* src = a.packed + (q < KS1 ? (int64_t)q * ST1 : L.l2_off + (int64_t)(q - KS1) * ST2);
+        uint8_t* dst = lds + (q % kWRing) * ST1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (16 * s + 8 * hf + i) < a.K0 ? xr[16 * s + i] : 0.f;
+        for (int i = 0; i < NW; ++i) {
+            const int blk = (wave + i * kWaves) % (NT * 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + blk * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
         }
     };
+    // Activation tile of k-step s: this wave's 32 rows x 64 bytes, fetched straight into LDS by two 1-KiB LDS-DMA
+    // instructions whose lanes cover whole 64-byte row segments (4 lanes per row: coalesced, unlike loading the MFMA
+    // B fragment — one row per lane — directly).  The DMA's LDS image is lane-linear, so the bank-conflict-free
+    // layout is made on the SOURCE side: LDS slot c' of row r holds 16-byte piece c' ^ ((r >> 2) & 3).
+    const int64_t row0 = (int64_t)blockIdx.x * (32 * kWaves) + wave * 32;
+    const float* xsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * j + (lane >> 2);
+        const int64_t rg = row0 + r < a.B ? row0 + r : a.B - 1;
+        xsrc[j] = a.x + rg * a.ldx + 4 * ((lane & 3) ^ ((r >> 2) & 3));
+    }
+    auto issue_x = [&](int s) {
+        if (dbg_nox) return;
+        uint8_t* dst = xring + (s % kXRing) * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + 16 * s),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    };
+    // B fragment of lane (m, hf) for k-step s: pieces 2hf, 2hf+1 of row m
+    const uint32_t xrd = (4 * m + ((2 * hf) ^ ((m >> 2) & 3))) * 16;
+    auto read_x = [&](int s, u32x4 (&v)[2]) {             // two hand-written ds_reads (see lds_read16)
+        const uint32_t t = xring_a + (s % kXRing) * 2048;
+        v[0] = lds_read16(t + xrd);
+        v[1] = lds_read16(t + (xrd ^ 16));
+    };
+    auto raw_floats = [&](const u32x4 (&v)[2], float (&x)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = __uint_as_float(v[0][i]); x[4 + i] = __uint_as_float(v[1][i]); }
+    };
+
+    // ---- prologue -------------------------------------------------------------------------------------------
+    // in order: W(0) W(1) X(0) X(1) X(2)
+    issue_w(0);
+    if (Q > 1) issue_w(1);
+    issue_x(0);
+    if (KS1 > 1) issue_x(1);
+    if (KS1 > 2) issue_x(2);
+    {   // tables -> LDS (plain loads; ordered before everything that reads them by the first barrier)
+        const float* src = reinterpret_cast<const float*>(a.packed + L.tab_off);
+        for (int i = threadIdx.x; i < 3 * NT * 32 + 4; i += 64 * kWaves) tabs[i] = src[i];
+    }
+    const int64_t row = row0 + m;
 
     // ---- layer 1: K0 -> NT*32 hidden units --------------------------------------------------------------------
+    // Per k-step s (= one stage of the weight stream): wait until W(s) and X(s+1) — requested two stages ago — have
+    // landed, barrier; then 6*NT MFMAs with, in their shadows, the rolling LDS reads of the next tile pair's planes,
+    // the bf16 split of X(s+1), and the requests for W(s+2) and X(s+3) (an LDS-DMA instruction holds the issuing wave
+    // for ~100 cycles: measured 840 cycles per stage when 8 of them sat in front of the MFMAs).
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float xn[8];
-    load_x(0, xn);
+    u32x4 rawv[2];
+    float raw[8];
+    u32x4 bh, bm, bl, nh, nm, nl;
+    // W(0), W(1), X(0) landed; X(1), X(2) may still be in flight
+    if (KS1 > 2) wait_vm<4>(); else if (KS1 > 1) wait_vm<2>(); else wait_vm<0>();
+    read_x(0, rawv);                                    // wave-private tile: no barrier needed
+    lds_wait<0, 2>(rawv);
+    raw_floats(rawv, raw);
+    split3(raw, bh, bm, bl);
+#ifdef ARMNET_DEV_FLAGS
+    unsigned long long ph[4] = {0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < KS1; ++s) {
-        const u32x4* st = advance();
-        float xc[8];
+        if (!dbg_nosync) {
+            // in flight and allowed to stay: what stage s-1 requested, W(s+1) and X(s+2) (at s = 0 the prologue's X(2))
+            const bool w_out = s >= 1 && s + 1 < Q, x_out = s + 2 < KS1;
+            if (w_out && x_out) wait_vm<NW + 2>();
+            else if (w_out) wait_vm<NW>();
+            else if (x_out) wait_vm<2>();
+            else wait_vm<0>();
+            MLP_PHASE(0);
+            block_barrier();
+            MLP_PHASE(1);
+        }
+        const uint32_t st = ring_a + (s % kWRing) * ST1;
+        if (s + 1 < KS1) read_x(s + 1, rawv);           // older than the plane reads: valid once the first plane is
+        APlanes<PAIR> A;
+        load_planes<PAIR>(A, st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        MLP_PHASE(2);
+        lds_wait<3 * PAIR, 2>(rawv);
+        raw_floats(rawv, raw);
+        split3(raw, nh, nm, nl);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xc[i] = xn[i];
-        if (s + 1 < KS1) load_x(s + 1, xn);
-        u32x4 bh, bm, bl;
-        split3(xc, bh, bm, bl);
-        step_mfma<NT>(acc, st, lane, bh, bm, bl);
+        for (int p = 0; p < NP1; ++p) {
+            if (p + 1 < NP1) unit<PAIR, true>(acc + p * PAIR, A, bh, bm, bl, st, (p + 1) * PAIR);
+            else unit<PAIR, false>(acc + p * PAIR, A, bh, bm, bl, st, 0);
+            if (p == 0) {                               // requests ride behind the first unit's MFMAs
+                if (s + 2 < Q) issue_w(s + 2);
+                if (s + 3 < KS1) issue_x(s + 3);
+                __builtin_amdgcn_sched_barrier(0x2);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MLP_PHASE(3);
+        bh = nh; bm = nm; bl = nl;
     }
+#ifdef ARMNET_DEV_FLAGS
+    if (lane == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_mlp_phase[i], ph[i]);
+#endif
     // bias (BatchNorm folded) + ReLU, in place: acc becomes H1 in C layout
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -293,12 +440,21 @@ __global__ void __launch_bounds__(256, 2) mlp_head_kernel(MlpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = c_layout_unit(t, r, hf);
-                if (n < a.N) a.out[row * (int64_t)a.N + n] = h[r];
+                if (n < a.N) a.out[row * a.ldo + n] = h[r];
             }
         }
     };
     if (a.n_hidden >= 2) {
         // ---- layer 2: the previous layer's accumulators ARE this layer's B operands ----------------------------
+        // k-step s2 takes registers 8u..8u+7 (u = s2 & 1) of tile s2 >> 1; its planes are split one k-step ahead
+        auto split_step = [&](int s2, u32x4& ph_, u32x4& pm_, u32x4& pl_) {
+            float xc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xc[j] = acc[s2 >> 1][8 * (s2 & 1) + j];
+            split3(xc, ph_, pm_, pl_);
+        };
+        split_step(0, bh, bm, bl);
+        int q = KS1;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             f32x16 acc2[TG];
@@ -308,17 +464,35 @@ __global__ void __launch_bounds__(256, 2) mlp_head_kernel(MlpArgs a) {
                 for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 #pragma unroll
             for (int sg = 0; sg < NS2; ++sg) {
-                const u32x4* st = advance();
+                if (!dbg_nosync) {
+                    if (q >= 1 && q + 1 < Q) wait_vm<NW>(); else wait_vm<0>();   // W(q+1) may stay in flight
+                    block_barrier();
+                }
+                const uint32_t st = ring_a + (q % kWRing) * ST1;
+                APlanes<PAIR> A;
+                load_planes<PAIR>(A, st, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int U = KPS * NP2;                             // (k-step, tile pair) units of this stage
 #pragma unroll
                 for (int kk = 0; kk < KPS; ++kk) {
-                                    const int s2 = sg * KPS + kk;                        // k-step: registers 8u..8u+7 of tile s2 >> 1
-                    float xc[8];
+                    const int s2 = sg * KPS + kk;
+                    split_step((s2 + 1) % (2 * NT), nh, nm, nl);         // next k-step (wraps into the next group)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xc[j] = acc[s2 >> 1][8 * (s2 & 1) + j];
-                    u32x4 bh, bm, bl;
-                    split3(xc, bh, bm, bl);
-                    step_mfma<TG>(acc2, st + kk * TG * 3 * 64, lane, bh, bm, bl);
+                    for (int p = 0; p < NP2; ++p) {
+                        const int u = kk * NP2 + p;
+                        const uint32_t nxt = st + ((u + 1) / NP2) * TG * 3 * 1024;
+                        const int t0n = ((u + 1) % NP2) * PAIR;
+                        if (u + 1 < U) unit<PAIR, true>(acc2 + p * PAIR, A, bh, bm, bl, nxt, t0n);
+                        else unit<PAIR, false>(acc2 + p * PAIR, A, bh, bm, bl, nxt, t0n);
+                        if (u == 0) {
+                            if (q + 2 < Q) issue_w(q + 2);
+                            __builtin_amdgcn_sched_barrier(0x2);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bh = nh; bm = nm; bl = nl;
                 }
+                ++q;
             }
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
@@ -352,13 +526,14 @@ __global__ void __launch_bounds__(256, 2) mlp_head_kernel(MlpArgs a) {
 template <int NT>
 static int launch_mlp(const MlpArgs& a, hipStream_t st) {
     static_assert(mlp_kps(NT) * mlp_tg(NT) <= NT, "a layer-2 stage must fit a ring slot");
-    const size_t lds = (size_t)2 * NT * 3 * 1024 + ((size_t)3 * NT * 32 + 4) * sizeof(float);
+    const size_t lds = (size_t)kWRing * NT * 3 * 1024 + ((((size_t)3 * NT * 32 + 4) * sizeof(float) + 15) & ~(size_t)15) +
+                       (size_t)kWaves * kXRing * 2048;
     auto kern = mlp_head_kernel<NT>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t blocks = (a.B + 127) / 128;
-    kern<<<(int)blocks, 256, lds, st>>>(a);
+    const int64_t blocks = (a.B + 32 * kWaves - 1) / (32 * kWaves);
+    kern<<<(int)blocks, 64 * kWaves, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
@@ -400,13 +575,19 @@ int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const fl
 }
 
 int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final, const float* x, int64_t ldx,
-                        const void* packed, float* out, void* stream) {
-    if (B < 0 || !armnet_mlp_head_supported(K0, nhid, n_hidden) || ldx < K0) return ARMNET_ERR_BAD_ARG;
+                        const void* packed, float* out, int64_t ldo, void* stream) {
+    // rows of x are read in whole 16-float k-steps: the row stride must cover the rounded-up width (the columns past
+    // K0 meet zero weights; they only have to be readable and finite)
+    if (B < 0 || !armnet_mlp_head_supported(K0, nhid, n_hidden) || ldx < (int64_t)((K0 + 15) / 16) * 16) return ARMNET_ERR_BAD_ARG;
+    if (!has_final && ldo < nhid) return ARMNET_ERR_BAD_ARG;
     if (B == 0) return ARMNET_OK;
     if (!x || !packed || !out) return ARMNET_ERR_BAD_ARG;
     MlpArgs a{};
-    a.B = B; a.K0 = K0; a.n_hidden = n_hidden; a.has_final = has_final ? 1 : 0; a.N = nhid; a.ldx = ldx;
+    a.B = B; a.K0 = K0; a.n_hidden = n_hidden; a.has_final = has_final ? 1 : 0; a.N = nhid; a.ldx = ldx; a.ldo = ldo;
     a.x = x; a.packed = static_cast<const uint8_t*>(packed); a.out = out;
+#ifdef ARMNET_DEV_FLAGS
+    if (const char* e = getenv("ARMNET_MLP_DBG")) a.dbg = atoi(e);
+#endif
     switch (mlp_nt_for(nhid)) {
         case 1: return launch_mlp<1>(a, (hipStream_t)stream);
         case 2: return launch_mlp<2>(a, (hipStream_t)stream);
@@ -415,5 +596,15 @@ int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final
         default: return ARMNET_ERR_UNSUPPORTED;
     }
 }
+
+#ifdef ARMNET_DEV_FLAGS
+// developer build only: read and reset the per-phase cycle sums of mlp_head_kernel
+void armnet_dev_mlp_phases(unsigned long long* out8) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_phase), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_phase), z, sizeof(z));
+}
+#endif
 
 }  // extern "C"

@@ -245,7 +245,10 @@ int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R
  *       W' = W * s, b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps); W' is then split into bf16
  *       hi/mid/lo (round-to-nearest) in the kernel's operand order.
  *   armnet_mlp_head_f32         x [B, K0] (row stride ldx floats) -> has_final ? out [B] (the logits, layers.py:88)
- *                                                                              : out [B, nhid] (post-ReLU activations)
+ *                                                                              : out [B, nhid] (post-ReLU activations,
+ *                                                                                row stride ldo floats)
+ *       x is read in whole 16-float k-steps: ldx >= 16 * ceil(K0 / 16), and the columns K0 .. of every row must be
+ *       readable and finite (they meet zero weights).  A contiguous [B, K0] tensor qualifies when K0 % 16 == 0.
  */
 int armnet_mlp_head_supported(int K0, int nhid, int n_hidden);
 int64_t armnet_mlp_packed_bytes(int K0, int nhid, int n_hidden);
@@ -253,7 +256,7 @@ int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const fl
                               const float* bn_weight, const float* bn_bias, const float* bn_running_mean,
                               const float* bn_running_var, float bn_eps, void* packed, void* stream);
 int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final, const float* x, int64_t ldx,
-                        const void* packed, float* out, void* stream);
+                        const void* packed, float* out, int64_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,11 +9,15 @@ from armnet_hip.modules import _MLP
 
 DEV = "cuda:0"
 B = int(os.environ.get("B", 65536))
-for K0, nlayers, nhid in ((512, 2, 256), (2048, 2, 256), (704, 2, 256), (512, 2, 128), (512, 1, 256), (320, 2, 32)):
+CFGS = ((512, 2, 256), (2048, 2, 256), (704, 2, 256), (512, 2, 128), (512, 1, 256), (320, 2, 32))
+if os.environ.get("ONLY"):
+    CFGS = CFGS[:int(os.environ["ONLY"])]
+MODES = (("hip", True),) if os.environ.get("HIP_ONLY") else (("hip", True), ("blas", False))
+for K0, nlayers, nhid in CFGS:
     m = _MLP(K0, nlayers, nhid, 0.0).eval().to(DEV)
     xs = [torch.randn(B, K0, device=DEV) for _ in range(3)]
     res = {}
-    for name, flag in (("hip", True), ("blas", False)):
+    for name, flag in MODES:
         m.hip_head = flag
         with torch.no_grad():
             for i in range(5):
@@ -27,5 +31,7 @@ for K0, nlayers, nhid in ((512, 2, 256), (2048, 2, 256), (704, 2, 256), (512, 2,
             torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 30 * 1e3
     fl = 2.0 * B * (K0 * nhid + (nlayers - 1) * nhid * nhid + nhid)
-    print(f"K0={K0} nlayers={nlayers} nhid={nhid} B={B}: HIP head {res['hip']:.1f} us ({fl / res['hip'] / 1e6:.0f} fp32-equivalent TFLOP/s), "
-          f"hipBLASLt {res['blas']:.1f} us ({fl / res['blas'] / 1e6:.0f} TFLOP/s)")
+    line = f"K0={K0} nlayers={nlayers} nhid={nhid} B={B}: HIP head {res['hip']:.1f} us ({fl / res['hip'] / 1e6:.0f} fp32-equivalent TFLOP/s)"
+    if "blas" in res:
+        line += f", hipBLASLt {res['blas']:.1f} us ({fl / res['blas'] / 1e6:.0f} TFLOP/s)"
+    print(line)
