@@ -18,7 +18,7 @@ ABI_VERSION = 1
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
-ONE_HEAD, MULTI_HEAD = 0, 1
+ONE_HEAD, MULTI_HEAD, GC_ARM = 0, 1, 2
 F_WRITE_CLAMPED_VALS, F_FAITHFUL_BISECT, F_FORCE_GENERIC = 0x1, 0x2, 0x4
 
 EXPORTS = (
@@ -29,7 +29,8 @@ EXPORTS = (
     "armnet_fused_kernel_kind", "armnet_fused_bwd_bn_f32", "armnet_bn_stats_f32", "armnet_bn_finalize_f32",
     "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
     "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
-    "armnet_mlp_head_f32",
+    "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
+    "armnet_abs_clamp_min_f32",
 )
 
 _lib = None
@@ -370,3 +371,46 @@ def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
         check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(bool(has_final)),
                                          _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
                                          _stream()))
+
+
+def gc_fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, emb_scale, emb_shift, bn_scale,
+                 bn_shift, out, id_status=None):
+    _ids_ok(ids)
+    ts = (vals, table, q_fold, values, emb_scale, emb_shift, bn_scale, bn_shift, out)
+    for n, t in zip(("vals", "table", "q_fold", "values", "emb_scale", "emb_shift", "bn_scale", "bn_shift", "out"), ts):
+        _dev_f32(t, n)
+    with _on(ids, id_status, *ts):
+        check(load().armnet_gc_fused_fwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                             ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                             ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values),
+                                             _ptr(emb_scale), _ptr(emb_shift), _ptr(bn_scale), _ptr(bn_shift),
+                                             _ptr(out), _ptr(id_status), _stream()))
+
+
+def afn_fused_fwd(B, F, E, O, flags, ids, vals, table, weight, bias, emb_scale, emb_shift, bn_scale, bn_shift, out,
+                  id_status=None):
+    _ids_ok(ids)
+    ts = (vals, table, weight, bias, emb_scale, emb_shift, bn_scale, bn_shift, out)
+    for n, t in zip(("vals", "table", "weight", "bias", "emb_scale", "emb_shift", "bn_scale", "bn_shift", "out"), ts):
+        _dev_f32(t, n)
+    with _on(ids, id_status, *ts):
+        check(load().armnet_afn_fused_fwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_uint32(flags), _ptr(ids),
+                                              _id_type(ids), _ptr(vals), _ptr(table), ctypes.c_int64(table.shape[0]),
+                                              _ptr(weight), _ptr(bias), _ptr(emb_scale), _ptr(emb_shift),
+                                              _ptr(bn_scale), _ptr(bn_shift), _ptr(out), _ptr(id_status), _stream()))
+
+
+def fold_bn(weight, bias, mean, var, eps, scale, shift):
+    ts = (weight, bias, mean, var, scale, shift)
+    for n, t in zip(("weight", "bias", "mean", "var", "scale", "shift"), ts):
+        _dev_f32(t, n)
+    with _on(*ts):
+        check(load().armnet_fold_bn_f32(int(weight.numel()), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(var),
+                                        ctypes.c_float(eps), _ptr(scale), _ptr(shift), _stream()))
+
+
+def abs_clamp_min(t, lo):
+    """t <- max(|t|, lo) in place (afn.py:74-77)"""
+    _dev_f32(t, "t")
+    with _on(t):
+        check(load().armnet_abs_clamp_min_f32(_ptr(t), ctypes.c_int64(t.numel()), ctypes.c_float(lo), _stream()))

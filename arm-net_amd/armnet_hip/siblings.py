@@ -1,0 +1,238 @@
+"""Sibling models of ARM-Net on the same HIP kernels: GC-ARM and AFN, inference.
+
+Both share ARM-Net's skeleton — clamp, embedding lookup * value, a per-sample [neurons, fields] x [fields, nemb]
+contraction, BatchNorm, MLP head, optional DNN ensemble — and differ in how the [neurons, fields] weights arise and in
+the element-wise maps around the contraction:
+
+    GC-ARM (models/gc_arm.py)  weights = entmax(gates + global context) * values; contraction over emb_bn(exp(x)); no
+                               outer exp
+    AFN (models/afn.py)        weights = afn.weight (fixed); contraction over emb_bn(log(x)); bias, outer exp
+
+Eval-mode inference runs on armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head; training
+mode is not built for the siblings (the reference trains them with plain autograd) and raises."""
+import torch
+import torch.nn as nn
+
+from . import native
+from .block import _require_cuda
+from .modules import HipBatchNorm1d, HipEmbedding, _MLP
+
+
+class _VersionKey:
+    """cache key over a set of tensors: (storage pointer, version counter) — see ArmNetBase.invalidate_folded"""
+
+    def __init__(self):
+        self.key = None
+
+    def changed(self, tensors, extra=()):
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + tuple(extra)
+        if key != self.key:
+            self.key = key
+            return True
+        return False
+
+
+class SiblingBase(nn.Module):
+    """shared plumbing: ensemble branch, logits, id checking, folded BatchNorm affines"""
+
+    def _init_tail(self, nfield, nfeat, nemb, ninput, mlp_layers, mlp_hid, dropout, ensemble, deep_layers, deep_hid):
+        self.mlp = _MLP(ninput, mlp_layers, mlp_hid, dropout)
+        if ensemble:
+            self.deep_embedding = HipEmbedding(nfeat, nemb)
+            self.deep_mlp = _MLP(nfield * nemb, deep_layers, deep_hid, dropout)
+            self.ensemble_layer = nn.Linear(2, 1)
+            nn.init.constant_(self.ensemble_layer.weight, 0.5)
+            nn.init.constant_(self.ensemble_layer.bias, 0.)
+        self.check_ids = True
+        self.kernel_flags = 0
+        self._fold_key = _VersionKey()
+        self._folds = None
+
+    def invalidate_folded(self):
+        self._fold_key.key = None
+        for m in self.modules():
+            if isinstance(m, _MLP):
+                m.invalidate()
+
+    def train(self, mode=True):
+        self.invalidate_folded()
+        return super().train(mode)
+
+    def _bn_affine(self, bn):
+        dev = bn.weight.device
+        sc, sh = torch.empty_like(bn.weight), torch.empty_like(bn.weight)
+        native.fold_bn(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, float(bn.eps), sc, sh)
+        return sc, sh
+
+    def _inputs(self, x, vals):
+        if vals is not None:
+            x = {"id": x, "value": vals}
+        ids, v = x["id"], x["value"]
+        _require_cuda(v, "x['value']")
+        _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
+        if v.dtype != torch.float32:
+            raise native.ArmnetNativeError(f"x['value'] must be float32, got {v.dtype}")
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                f"{type(self).__name__}: only eval-mode inference (model.eval() under torch.no_grad()) is built on the "
+                "HIP kernels; the reference trains this model with plain autograd")
+        v_run = v if v.is_contiguous() else v.contiguous()
+        ids = ids if ids.is_contiguous() else ids.contiguous()
+        return ids, v, v_run
+
+    def _finish(self, block, ids, v, v_run):
+        if v_run is not v:
+            v.copy_(v_run)                                       # keep the visible clamp side effect
+        y = self.mlp(block.view(block.shape[0], -1))
+        if self.ensemble:
+            x_deep = self.deep_embedding({"id": ids, "value": v}, check_ids=False)   # ids validated by the fused call
+            y_deep = self.deep_mlp(x_deep.view(x_deep.shape[0], -1))
+            y = self.ensemble_layer(torch.cat([y, y_deep], dim=1))
+        return y.squeeze(1)
+
+    def _status(self, dev):
+        return torch.zeros(1, device=dev, dtype=torch.int32) if self.check_ids else None
+
+    @staticmethod
+    def _raise_if_bad(status):
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("index out of range in self")
+
+
+class GC_SparseAttLayer(nn.Module):
+    """Sparse attention with global context (gc_arm.py:6-48): Q [nhead, nhid, nemb], bilinear [nhead, nemb, nemb],
+    values [nhead, nhid, nfield].  Called on x [B,F,E] it returns the attention weights [B,K,O,F] (stand-alone surface;
+    the model forward uses the fused kernel)."""
+
+    def __init__(self, nhead, nfield, nemb, nhid, alpha=1.5):
+        super().__init__()
+        from utils.entmax import EntmaxBisect
+        self.alpha = float(alpha)
+        self.sparsemax = nn.Softmax(dim=-1) if alpha == 1. else EntmaxBisect(alpha, dim=-1)
+        self.Q = nn.Parameter(torch.zeros(nhead, nhid, nemb))
+        nn.init.xavier_uniform_(self.Q, gain=1.414)
+        self.bilinear = nn.Parameter(torch.zeros(nhead, nemb, nemb))
+        nn.init.xavier_uniform_(self.bilinear, gain=1.414)
+        self.values = nn.Parameter(torch.zeros(nhead, nhid, nfield))
+        nn.init.xavier_uniform_(self.values, gain=1.414)
+
+    def forward(self, x):
+        t = torch.matmul(x.unsqueeze(1), self.bilinear.unsqueeze(0))                    # [B,K,F,E]
+        gates = torch.matmul(self.Q.unsqueeze(0), t.transpose(2, 3))                    # [B,K,O,F]
+        gates = gates + gates.sum(-1, keepdim=True)                                     # global context
+        return self.sparsemax(gates) * self.values
+
+
+class GC_ARMModel(SiblingBase):
+    """Adaptive Relation Modeling Network + Global Context (gc_arm.py:50-105), positional constructor of
+    model_utils.py:83-85: GC_ARMModel(nfield, nfeat, nemb, nhead, alpha, arm_hid, mlp_layers, mlp_hid, dropout,
+    ensemble, deep_layers, deep_hid)."""
+
+    def __init__(self, nfield, nfeat, nemb, nhead, alpha, arm_hid, mlp_layers, mlp_hid, dropout, ensemble, deep_layers,
+                 deep_hid):
+        super().__init__()
+        self.nfield, self.nfeat, self.nemb = nfield, nfeat, nemb
+        self.nhead, self.arm_hid = nhead, arm_hid
+        self.ensemble = ensemble
+        self.alpha = float(alpha)
+        self.n_iter = 50
+        self.dropout = nn.Dropout(p=dropout)
+        self.embedding = HipEmbedding(nfeat, nemb)
+        self.emb_bn = HipBatchNorm1d(nfield)
+        self.attn_layers = GC_SparseAttLayer(nhead, nfield, nemb, arm_hid, alpha)
+        self.arm_bn = HipBatchNorm1d(nhead * arm_hid)
+        self._init_tail(nfield, nfeat, nemb, nhead * arm_hid * nemb, mlp_layers, mlp_hid, dropout, ensemble, deep_layers,
+                        deep_hid)
+
+    def _fold(self):
+        at = self.attn_layers
+        src = [at.Q, at.bilinear] + [t for bn in (self.emb_bn, self.arm_bn)
+                                      for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        if self._fold_key.changed(src) or self._folds is None:
+            K, H, E = self.nhead, self.arm_hid, self.nemb
+            dev = at.Q.device
+            qf = torch.empty(K * H, E, device=dev)
+            sc, sh = torch.empty(K * H, device=dev), torch.empty(K * H, device=dev)
+            bn = self.arm_bn
+            native.fold_params(native.GC_ARM, K, H, E, E, at.bilinear.detach().contiguous(), at.Q.detach().contiguous(),
+                               bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, float(bn.eps),
+                               qf, sc, sh)
+            es, et = self._bn_affine(self.emb_bn)
+            self._folds = (qf, sc, sh, es, et)
+        return self._folds
+
+    def arm_block(self, ids, vals):
+        """ids [B,F], vals [B,F] (clamped in place) -> arm_bn(arm) [B, nhead*arm_hid, nemb] (gc_arm.py:86-94)"""
+        B, F = vals.shape
+        O, E = self.nhead * self.arm_hid, self.nemb
+        qf, sc, sh, es, et = self._fold()
+        out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+        status = self._status(vals.device)
+        native.gc_fused_fwd(B, F, E, O, self.alpha, self.n_iter, self.kernel_flags | native.F_WRITE_CLAMPED_VALS, ids,
+                            vals, self.embedding.embedding.weight.detach(), qf,
+                            self.attn_layers.values.detach().reshape(O, F), es, et, sc, sh, out, status)
+        self._raise_if_bad(status)
+        return out
+
+    def forward(self, x, vals=None):
+        """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (gc_arm.py:82-105: squeeze(1))"""
+        ids, v, v_run = self._inputs(x, vals)
+        return self._finish(self.arm_block(ids, v_run), ids, v, v_run)
+
+
+class AFNModel(SiblingBase):
+    """Adaptive Factorization Network (afn.py:5-77), positional constructor of model_utils.py:40-42:
+    AFNModel(nfield, nfeat, nemb, afn_hid, mlp_layers, mlp_hid, dropout, ensemble, deep_layers, deep_hid)."""
+
+    def __init__(self, nfield, nfeat, nemb, afn_hid, mlp_layers, mlp_hid, dropout, ensemble, deep_layers, deep_hid):
+        super().__init__()
+        self.nfield, self.nfeat = nfield, nfeat
+        self.nemb, self.afn_hid = nemb, afn_hid
+        self.ensemble = ensemble
+        self.dropout = nn.Dropout(p=dropout)
+        self.embedding = HipEmbedding(nfeat, nemb)
+        self.emb_bn = HipBatchNorm1d(nfield)
+        self.afn = nn.Linear(nfield, afn_hid)
+        self.afn_bn = HipBatchNorm1d(afn_hid)
+        nn.init.normal_(self.afn.weight, std=0.1)
+        nn.init.constant_(self.afn.bias, 0.)
+        self._init_tail(nfield, nfeat, nemb, afn_hid * nemb, mlp_layers, mlp_hid, dropout, ensemble, deep_layers, deep_hid)
+        self._clip_key = _VersionKey()
+
+    def embedding_clip(self):
+        """keep AFN embeddings positive (afn.py:74-77): weight.abs_().clamp_(min=1e-4) in place.  Idempotent, so it
+        is only re-run when the table changed since the last clip."""
+        w = self.embedding.embedding.weight
+        if self._clip_key.changed([w]):
+            with torch.no_grad():
+                if w.is_cuda:
+                    native.abs_clamp_min(w.detach(), 1e-4)       # raw in-place write: the version counter is unmoved
+                else:
+                    w.abs_().clamp_(min=1e-4)
+                    self._clip_key.changed([w])
+
+    def _fold(self):
+        src = [t for bn in (self.emb_bn, self.afn_bn) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        if self._fold_key.changed(src) or self._folds is None:
+            self._folds = self._bn_affine(self.emb_bn) + self._bn_affine(self.afn_bn)
+        return self._folds
+
+    def afn_block(self, ids, vals):
+        """ids [B,F], vals [B,F] (clamped in place) -> afn_bn(exp(afn(emb_bn(log x)))) [B, afn_hid, nemb]
+        (afn.py:56-67)"""
+        B, F = vals.shape
+        O, E = self.afn_hid, self.nemb
+        es, et, sc, sh = self._fold()
+        out = torch.empty(B, O, E, device=vals.device, dtype=torch.float32)
+        status = self._status(vals.device)
+        native.afn_fused_fwd(B, F, E, O, self.kernel_flags | native.F_WRITE_CLAMPED_VALS, ids, vals,
+                             self.embedding.embedding.weight.detach(), self.afn.weight.detach().contiguous(),
+                             self.afn.bias.detach(), es, et, sc, sh, out, status)
+        self._raise_if_bad(status)
+        return out
+
+    def forward(self, x, vals=None):
+        """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (afn.py:49-72: squeeze(1))"""
+        ids, v, v_run = self._inputs(x, vals)
+        self.embedding_clip()
+        return self._finish(self.afn_block(ids, v_run), ids, v, v_run)

@@ -51,7 +51,7 @@ int armnet_fold_params_f32(int variant, int K, int H, int E, int D, const float*
                            const float* bn_running_mean, const float* bn_running_var, float bn_eps,
                            float* q_fold, float* bn_scale, float* bn_shift, void* stream) {
     if (K <= 0 || H <= 0 || E <= 0 || D <= 0) return ARMNET_ERR_BAD_ARG;
-    if (variant != ARMNET_ONE_HEAD && variant != ARMNET_MULTI_HEAD) return ARMNET_ERR_BAD_ARG;
+    if (variant != ARMNET_ONE_HEAD && variant != ARMNET_MULTI_HEAD && variant != ARMNET_GC_ARM) return ARMNET_ERR_BAD_ARG;
     if (variant == ARMNET_ONE_HEAD && K != 1) return ARMNET_ERR_BAD_ARG;
     if (!bilinear_w || !query || !bn_weight || !bn_bias || !bn_running_mean || !bn_running_var || !q_fold ||
         !bn_scale || !bn_shift)
@@ -73,7 +73,7 @@ static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (!a.vals || !a.q_fold || !a.values || !a.bn_scale || !a.bn_shift || !a.out) return ARMNET_ERR_BAD_ARG;
     if (!(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     a.cfg = make_sparse_cfg(alpha, n_iter, a.F, 1, a.flags);
-    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(a.F, a.E, a.O)) {
+    if (a.model == MODEL_ARM && !(a.flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(a.F, a.E, a.O)) {
         const int rc = launch_fused_mfma(a, (hipStream_t)stream);
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }
@@ -95,6 +95,54 @@ int armnet_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter
     a.q_fold = q_fold; a.values = values; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.out = out; a.id_status = id_status; a.flags = flags;
     return fused_common(a, alpha, n_iter, stream);
+}
+
+int armnet_gc_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                            const void* ids, int id_type, float* vals, const float* table, int64_t nfeat,
+                            const float* q_fold, const float* values, const float* emb_scale, const float* emb_shift,
+                            const float* bn_scale, const float* bn_shift, float* out, int32_t* id_status, void* stream) {
+    if (B == 0 && F > 0 && E > 0 && O > 0) return ARMNET_OK;
+    if (!ids || !table || nfeat <= 0 || !emb_scale || !emb_shift) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    FusedArgs a{};
+    a.B = B; a.F = F; a.E = E; a.O = O;
+    a.ids = ids; a.id_type = id_type; a.rows = nullptr; a.vals = vals;
+    a.table = table; a.nfeat = nfeat;
+    a.q_fold = q_fold; a.values = values; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+    a.out = out; a.id_status = id_status; a.flags = flags;
+    a.model = MODEL_GC_ARM; a.emb_scale = emb_scale; a.emb_shift = emb_shift;
+    return fused_common(a, alpha, n_iter, stream);
+}
+
+int armnet_afn_fused_fwd_f32(int64_t B, int F, int E, int O, uint32_t flags, const void* ids, int id_type, float* vals,
+                             const float* table, int64_t nfeat, const float* weight, const float* bias,
+                             const float* emb_scale, const float* emb_shift, const float* bn_scale,
+                             const float* bn_shift, float* out, int32_t* id_status, void* stream) {
+    if (B == 0 && F > 0 && E > 0 && O > 0) return ARMNET_OK;
+    if (!ids || !table || nfeat <= 0 || !emb_scale || !emb_shift || !weight || !bias) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    FusedArgs a{};
+    a.B = B; a.F = F; a.E = E; a.O = O;
+    a.ids = ids; a.id_type = id_type; a.rows = nullptr; a.vals = vals;
+    a.table = table; a.nfeat = nfeat;
+    a.q_fold = weight;              // unused by the AFN path; non-null for the common argument check
+    a.values = weight; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+    a.out = out; a.id_status = id_status; a.flags = flags;
+    a.model = MODEL_AFN; a.emb_scale = emb_scale; a.emb_shift = emb_shift; a.lin_bias = bias;
+    return fused_common(a, 1.0f, 0, stream);
+}
+
+int armnet_fold_bn_f32(int C, const float* weight, const float* bias, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    if (C <= 0 || !weight || !bias || !running_mean || !running_var || !scale || !shift) return ARMNET_ERR_BAD_ARG;
+    return launch_fold_bn(C, weight, bias, running_mean, running_var, eps, scale, shift, (hipStream_t)stream);
+}
+
+int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream) {
+    if (n < 0 || (!p && n > 0)) return ARMNET_ERR_BAD_ARG;
+    return launch_abs_clamp_min(p, n, lo, (hipStream_t)stream);
 }
 
 int armnet_fused_fwd_from_rows_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,

@@ -243,6 +243,18 @@ struct FusedArgs {
     int32_t* id_status;
     uint32_t flags;
     SparseMapCfg cfg;
+    // sibling models on the same kernels; model == MODEL_ARM leaves the fields below unused
+    int model;                // FusedModel
+    const float* emb_scale;   // [F] eval-mode emb_bn as an affine per field (gc_arm.py:58,89 / afn.py:21,63)
+    const float* emb_shift;   // [F]
+    const float* lin_bias;    // AFN: afn.bias [O]
+};
+
+// which block the fused kernels compute
+enum FusedModel : int {
+    MODEL_ARM = 0,     // models/armnet.py / armnet_1h.py
+    MODEL_GC_ARM = 1,  // models/gc_arm.py: gates + their row sum (global context), interaction on emb_bn(exp(x)), no outer exp
+    MODEL_AFN = 2      // models/afn.py: exp(Linear_F(emb_bn(log x))): fixed weights `values` = afn.weight, no sparse map
 };
 
 struct BwdArgs {
@@ -269,6 +281,9 @@ struct BwdArgs {
     uint32_t flags;
 };
 
+int launch_fold_bn(int C, const float* w, const float* b, const float* m, const float* v, float eps, float* scale,
+                   float* shift, hipStream_t s);
+int launch_abs_clamp_min(float* p, int64_t n, float lo, hipStream_t s);
 int launch_scatter_add(int64_t n_rows, int E, const void* ids, int id_type, const float* vals, const float* g,
                        int64_t nfeat, float* d_table, hipStream_t s);
 int launch_fused_generic(const FusedArgs& a, hipStream_t s);

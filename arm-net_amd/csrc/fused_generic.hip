@@ -43,6 +43,26 @@ fused_generic_kernel(FusedArgs a, int S) {
             if (e == 0 && (a.flags & ARMNET_F_WRITE_CLAMPED_VALS) && v != vraw) a.vals[gi] = v;
         }
         __syncthreads();
+        if (a.model == MODEL_AFN) {
+            // afn.py:63-66: z[o,e] = sum_f W[o,f] * (log(x[f,e]) * s_f + t_f) + b[o]; out = afn_bn(exp(z))
+            for (int k = tid; k < ns * F * E; k += GEN_TPB) {
+                const int f = (k / E) % F;
+                xs[k] = fmaf(logf(xs[k]), a.emb_scale[f], a.emb_shift[f]);
+            }
+            __syncthreads();
+            for (int r = tid; r < ns * O; r += GEN_TPB) {
+                const int s = r / O, o = r - s * O;
+                const float* x = xs + (size_t)s * F * E;
+                const float sc = a.bn_scale[o], sh = a.bn_shift[o], bias = a.lin_bias[o];
+                float* dst = a.out + ((b0 + s) * O + o) * (int64_t)E;
+                for (int e = 0; e < E; ++e) {
+                    float acc = 0.f;
+                    for (int f = 0; f < F; ++f) acc = fmaf(x[f * E + e], a.values[(size_t)o * F + f], acc);
+                    dst[e] = fmaf(exp_accurate(acc + bias), sc, sh);
+                }
+            }
+            continue;
+        }
         for (int r = tid; r < ns * O; r += GEN_TPB) {
             const int s = r / O, o = r - s * O;
             const float* x = xs + (size_t)s * F * E;
@@ -54,10 +74,26 @@ fused_generic_kernel(FusedArgs a, int S) {
                 for (int e = 0; e < E; ++e) acc = fmaf(x[f * E + e], qf[e], acc);
                 col[f * GS] = acc;
             }
+            if (a.model == MODEL_GC_ARM) {
+                // gc_arm.py:37-41: global context = the gates of the field sum = the sum of the gates (real arithmetic)
+                float gc = 0.f;
+                for (int f = 0; f < F; ++f) gc += col[f * GS];
+                for (int f = 0; f < F; ++f) col[f * GS] += gc;
+            }
             sparse_map_row(col, GS, F, a.cfg);                            // a6
             for (int f = 0; f < F; ++f) col[f * GS] *= a.values[(size_t)o * F + f];   // a7
             const float sc = a.bn_scale[o], sh = a.bn_shift[o];
             float* dst = a.out + ((b0 + s) * O + o) * (int64_t)E;
+            if (a.model == MODEL_GC_ARM) {
+                // gc_arm.py:89-94: arm = sum_f w[f] * emb_bn(exp(x))[f,e]   (no outer exp), then arm_bn
+                for (int e = 0; e < E; ++e) {
+                    float acc = 0.f;
+                    for (int f = 0; f < F; ++f)
+                        acc = fmaf(col[f * GS], fmaf(exp_accurate(x[f * E + e]), a.emb_scale[f], a.emb_shift[f]), acc);
+                    dst[e] = fmaf(acc, sc, sh);
+                }
+                continue;
+            }
             for (int e = 0; e < E; ++e) {                                 // a8 + a9
                 float acc = 0.f;
                 for (int f = 0; f < F; ++f) acc = fmaf(col[f * GS], x[f * E + e], acc);

@@ -25,7 +25,8 @@ __global__ void fold_params_kernel(int variant, int K, int H, int E, int D, cons
             for (int y = 0; y < D; ++y)
                 acc += (double)bw[((size_t)k * E + e) * D + y] * (double)q[((size_t)k * H + o) * D + y];
         }
-        const float scale = (float)(1.0 / sqrt((double)D));   // python: d_k ** -0.5, cast to fp32 by the tensor multiply
+        // python: d_k ** -0.5, cast to fp32 by the tensor multiply; gc_arm.py:33-34 has no scale
+        const float scale = variant == ARMNET_GC_ARM ? 1.0f : (float)(1.0 / sqrt((double)D));
         q_fold[i] = (float)(acc * (double)scale);
     }
     if (i < O) {
@@ -35,6 +36,42 @@ __global__ void fold_params_kernel(int variant, int K, int H, int E, int D, cons
         bn_scale[i] = a;
         bn_shift[i] = bn_b[i] - bn_m[i] * a;
     }
+}
+
+// eval-mode BatchNorm1d as a per-channel affine (ATen's CPU transform form), for the field-wise emb_bn of GC-ARM / AFN
+__global__ void fold_bn_kernel(int C, const float* __restrict__ w, const float* __restrict__ b,
+                               const float* __restrict__ m, const float* __restrict__ v, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        const float a = w[i] * (1.0f / sqrtf(v[i] + eps));
+        scale[i] = a;
+        shift[i] = b[i] - m[i] * a;
+    }
+}
+
+int launch_fold_bn(int C, const float* w, const float* b, const float* m, const float* v, float eps, float* scale,
+                   float* shift, hipStream_t s) {
+    fold_bn_kernel<<<(C + 255) / 256, 256, 0, s>>>(C, w, b, m, v, eps, scale, shift);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
+// afn.py:74-77 embedding_clip: weight.abs_().clamp_(min=1e-4), in place
+__global__ void abs_clamp_min_kernel(float* __restrict__ p, int64_t n, float lo) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(p[i]);
+        p[i] = a < lo ? lo : a;                 // NaN stays NaN (torch.clamp)
+    }
+}
+
+int launch_abs_clamp_min(float* p, int64_t n, float lo, hipStream_t s) {
+    if (n == 0) return ARMNET_OK;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    abs_clamp_min_kernel<<<(int)grid, 256, 0, s>>>(p, n, lo);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
 }
 
 int launch_fold_params(int variant, int K, int H, int E, int D, const float* bw, const float* q,

@@ -44,7 +44,8 @@ typedef enum armnet_id_type { ARMNET_ID_I64 = 0, ARMNET_ID_I32 = 1 } armnet_id_t
 /* model variant for parameter folding */
 typedef enum armnet_variant {
     ARMNET_ONE_HEAD = 0,  /* models/armnet_1h.py: bilinear_w is nn.Linear weight [D,E], query [H,D] */
-    ARMNET_MULTI_HEAD = 1 /* models/armnet.py:    bilinear_w [K,E,D], query [K,H,D] */
+    ARMNET_MULTI_HEAD = 1,/* models/armnet.py:    bilinear_w [K,E,D], query [K,H,D] */
+    ARMNET_GC_ARM = 2     /* models/gc_arm.py:    bilinear [K,E,E], Q [K,H,E]; no d_k^-0.5 scale (gc_arm.py:33-34) */
 } armnet_variant;
 
 /* flags for the fused forward */
@@ -228,6 +229,37 @@ int64_t armnet_shard_route_unique_ws_bytes(int R, int64_t nfeat);
 int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
                                   int32_t* counts, int32_t* send_local, int32_t* perm, int32_t* n_unique,
                                   void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
+
+/*
+ * Sibling models on the same kernels, eval mode.
+ *
+ * armnet_gc_fused_fwd_f32 — models/gc_arm.py:82-95 (GC_ARMModel.forward up to arm_bn):
+ *   vals <- clamp(vals, 1e-3, 1);  x = table[ids] * vals                              gc_arm.py:86-87
+ *   g[b,o,f] = sum_e x[b,f,e] q_fold[o,e]     (fold with ARMNET_GC_ARM: no scale)     gc_arm.py:33-34
+ *   g[b,o,:] += sum_f g[b,o,f]                (global context: the gates of sum_f x)  gc_arm.py:37-41
+ *   w = entmax_alpha(g) * values                                                      gc_arm.py:43-46
+ *   arm[b,o,e] = sum_f w[b,o,f] * (exp(x[b,f,e]) * emb_scale[f] + emb_shift[f])       gc_arm.py:89,92  (no outer exp)
+ *   out = arm * bn_scale[o] + bn_shift[o]                                             gc_arm.py:94
+ * armnet_afn_fused_fwd_f32 — models/afn.py:56-69 (AFNModel.forward up to afn_bn; the table must already be clipped,
+ * armnet_abs_clamp_min_f32):
+ *   x as above;  l = log(x) * emb_scale[f] + emb_shift[f]                             afn.py:63
+ *   out[b,o,e] = exp(sum_f weight[o,f] * l[b,f,e] + bias[o]) * bn_scale[o] + bn_shift[o]    afn.py:64-66
+ * armnet_fold_bn_f32 — eval-mode BatchNorm1d as an affine: scale = w / sqrt(var + eps), shift = b - mean * scale.
+ * armnet_abs_clamp_min_f32 — afn.py:74-77 embedding_clip, in place: p <- max(|p|, lo).
+ * Both fused entry points write vals back (ARMNET_F_WRITE_CLAMPED_VALS) and flag out-of-range ids like
+ * armnet_fused_fwd_f32.
+ */
+int armnet_gc_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
+                            const void* ids, int id_type, float* vals, const float* table, int64_t nfeat,
+                            const float* q_fold, const float* values, const float* emb_scale, const float* emb_shift,
+                            const float* bn_scale, const float* bn_shift, float* out, int32_t* id_status, void* stream);
+int armnet_afn_fused_fwd_f32(int64_t B, int F, int E, int O, uint32_t flags, const void* ids, int id_type, float* vals,
+                             const float* table, int64_t nfeat, const float* weight, const float* bias,
+                             const float* emb_scale, const float* emb_shift, const float* bn_scale,
+                             const float* bn_shift, float* out, int32_t* id_status, void* stream);
+int armnet_fold_bn_f32(int C, const float* weight, const float* bias, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
 
 /*
  * The eval-mode prediction head — models/layers.py:68-88 `MLP`: n x (Linear, BatchNorm1d, ReLU, Dropout) then

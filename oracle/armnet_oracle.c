@@ -342,3 +342,90 @@ int oracle_arm_block(int variant, int64_t B, int F, int E, int D, int K, int H, 
     }
     return err ? ORACLE_ERR_ID_RANGE : ORACLE_OK;
 }
+
+/* ---- sibling models: GC-ARM (models/gc_arm.py) and AFN (models/afn.py) ---------------------- */
+
+/* torch.exp / torch.log, element-wise (gc_arm.py:89, afn.py:63) */
+void oracle_exp(const float* x, int64_t n, float* y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) y[i] = expf(x[i]);
+}
+void oracle_log(const float* x, int64_t n, float* y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) y[i] = logf(x[i]);
+}
+
+/* gc_arm.py:30-41 — bilinear = einsum('bfx,kxy,koy->bkof', keys, bilinear, Q)   (no scale)
+ *                   context = sum_f x[b,f,:];  gc = einsum('bx,kxy,koy->bko', context, bilinear, Q)
+ *                   attn_gates = bilinear + gc.unsqueeze(-1)
+ * both einsums contracted left to right like oracle_gates_mh. */
+void oracle_gates_gc(const float* x, const float* bil, const float* Q, int64_t B, int F, int E, int K, int H,
+                     float* gates) {
+    float* t = (float*)malloc(sizeof(float) * (size_t)(F + 1) * K * E);
+    float* ctx = (float*)malloc(sizeof(float) * (size_t)E);
+    for (int64_t b = 0; b < B; ++b) {
+        const float* xb = x + b * F * E;
+        for (int e = 0; e < E; ++e) {
+            float acc = 0.f;
+            for (int f = 0; f < F; ++f) acc += xb[f * E + e];
+            ctx[e] = acc;
+        }
+        for (int f = 0; f <= F; ++f) {                    /* row F: the context vector */
+            const float* row = f < F ? xb + f * E : ctx;
+            for (int k = 0; k < K; ++k)
+                for (int y = 0; y < E; ++y) {
+                    float acc = 0.f;
+                    for (int e = 0; e < E; ++e) acc = fmaf(row[e], bil[(k * E + e) * E + y], acc);
+                    t[(f * K + k) * E + y] = acc;
+                }
+        }
+        float* gb = gates + b * K * H * F;
+        for (int k = 0; k < K; ++k)
+            for (int o = 0; o < H; ++o) {
+                float gc = 0.f;
+                for (int y = 0; y < E; ++y) gc = fmaf(t[(F * K + k) * E + y], Q[(k * H + o) * E + y], gc);
+                for (int f = 0; f < F; ++f) {
+                    float acc = 0.f;
+                    for (int y = 0; y < E; ++y) acc = fmaf(t[(f * K + k) * E + y], Q[(k * H + o) * E + y], acc);
+                    gb[(k * H + o) * F + f] = acc + gc;
+                }
+            }
+    }
+    free(t);
+    free(ctx);
+}
+
+/* gc_arm.py:46 + :92 — w = p * values;  arm[b,o,e] = sum_f x_exp[b,f,e] * w[b,o,f]   (no exp) */
+void oracle_interact_sum(const float* xexp, const float* p, const float* values, int64_t B, int F, int E, int O,
+                         float* arm_weight, float* arm) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const float* xb = xexp + b * F * E;
+        for (int o = 0; o < O; ++o) {
+            const float* pr = p + (b * O + o) * F;
+            float* wr = arm_weight + (b * O + o) * F;
+            for (int f = 0; f < F; ++f) wr[f] = pr[f] * values[o * F + f];
+            for (int e = 0; e < E; ++e) {
+                float acc = 0.f;
+                for (int f = 0; f < F; ++f) acc = fmaf(xb[f * E + e], wr[f], acc);
+                arm[(b * O + o) * E + e] = acc;
+            }
+        }
+    }
+}
+
+/* afn.py:64-66 — afn[b,o,e] = exp(sum_f xlog[b,f,e] * W[o,f] + bias[o])   (Linear over the field dim of the
+ * transposed tensor, then transposed back) */
+void oracle_afn_linear_exp(const float* xlog, const float* W, const float* bias, int64_t B, int F, int E, int O,
+                           float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const float* xb = xlog + b * F * E;
+        for (int o = 0; o < O; ++o)
+            for (int e = 0; e < E; ++e) {
+                float acc = 0.f;
+                for (int f = 0; f < F; ++f) acc = fmaf(xb[f * E + e], W[o * F + f], acc);
+                out[(b * O + o) * E + e] = expf(acc + bias[o]);
+            }
+    }
+}

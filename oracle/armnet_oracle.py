@@ -245,6 +245,71 @@ def forward(variant, ctor, sd, ids, vals, train=False, n_iter=50):
     return out
 
 
+def _tail(block, sd, ids, vals, train=False):
+    """MLP head + optional DNN ensemble of the sibling models (gc_arm.py:96-105, afn.py:68-72): y.squeeze(1)"""
+    B = block.shape[0]
+    y = mlp(block.reshape(B, -1), sd, "mlp.mlp.", train=train)
+    if "ensemble_layer.weight" in sd:
+        xd = embed(ids, vals, sd["deep_embedding.embedding.weight"]).reshape(B, -1)
+        yd = mlp(xd, sd, "deep_mlp.mlp.", train=train)
+        y = linear(np.concatenate([y, yd], axis=1), sd["ensemble_layer.weight"], sd["ensemble_layer.bias"])
+    return y[:, 0]
+
+
+def forward_gc_arm(ctor, sd, ids, vals, n_iter=50):
+    """GC_ARMModel.forward in eval mode (models/gc_arm.py:82-105), stage by stage."""
+    out = {}
+    vals = np.array(vals, dtype=np.float32, copy=True)
+    clamp_vals(vals)
+    out["vals_clamped"] = vals
+    x = embed(ids, vals, sd["embedding.embedding.weight"])                     # gc_arm.py:87
+    B, F, E = x.shape
+    xe = np.empty_like(x)
+    lib().oracle_exp(_fp(x), ctypes.c_int64(x.size), _fp(xe))                   # gc_arm.py:89
+    x_exp = bn_eval(xe, sd["emb_bn.weight"], sd["emb_bn.bias"], sd["emb_bn.running_mean"], sd["emb_bn.running_var"])
+    Q, pQ = _f(sd["attn_layers.Q"]); bil, pbil = _f(sd["attn_layers.bilinear"])
+    K, H = Q.shape[0], Q.shape[1]
+    g = np.empty((B, K, H, F), np.float32)
+    lib().oracle_gates_gc(_fp(x), pbil, pQ, ctypes.c_int64(B), F, E, K, H, _fp(g))   # gc_arm.py:30-41
+    out["gates"] = g
+    p = sparse_map(g, float(ctor["alpha"]), n_iter)                            # gc_arm.py:43
+    out["p"] = p
+    O = K * H
+    values, pv = _f(np.asarray(sd["attn_layers.values"]).reshape(O, F))
+    pp, ppp = _f(p.reshape(B, O, F)); xx, pxx = _f(x_exp)
+    w = np.empty((B, O, F), np.float32); arm = np.empty((B, O, E), np.float32)
+    lib().oracle_interact_sum(pxx, ppp, pv, ctypes.c_int64(B), F, E, O, _fp(w), _fp(arm))   # gc_arm.py:45-46,92
+    xa = bn_eval(arm, sd["arm_bn.weight"], sd["arm_bn.bias"], sd["arm_bn.running_mean"], sd["arm_bn.running_var"])
+    out["x_arm"] = xa
+    out["logits"] = _tail(xa, sd, ids, vals)
+    return out
+
+
+def forward_afn(ctor, sd, ids, vals):
+    """AFNModel.forward in eval mode (models/afn.py:49-77), stage by stage.  Returns the clipped table too."""
+    out = {}
+    vals = np.array(vals, dtype=np.float32, copy=True)
+    clamp_vals(vals)
+    out["vals_clamped"] = vals
+    table = np.maximum(np.abs(np.asarray(sd["embedding.embedding.weight"], dtype=np.float32)), np.float32(1e-4))
+    out["table_after"] = table                                                 # afn.py:74-77
+    sd = dict(sd); sd["embedding.embedding.weight"] = table
+    x = embed(ids, vals, table)                                                # afn.py:61
+    B, F, E = x.shape
+    xl = np.empty_like(x)
+    lib().oracle_log(_fp(x), ctypes.c_int64(x.size), _fp(xl))                   # afn.py:63
+    x_log = bn_eval(xl, sd["emb_bn.weight"], sd["emb_bn.bias"], sd["emb_bn.running_mean"], sd["emb_bn.running_var"])
+    W, pW = _f(sd["afn.weight"]); b, pb = _f(sd["afn.bias"])
+    O = W.shape[0]
+    xx, pxx = _f(x_log)
+    a = np.empty((B, O, E), np.float32)
+    lib().oracle_afn_linear_exp(pxx, pW, pb, ctypes.c_int64(B), F, E, O, _fp(a))   # afn.py:64-65
+    xa = bn_eval(a, sd["afn_bn.weight"], sd["afn_bn.bias"], sd["afn_bn.running_mean"], sd["afn_bn.running_var"])
+    out["x_arm"] = xa                                                          # afn.py:66 (same slot as the ARM block)
+    out["logits"] = _tail(xa, sd, ids, vals)
+    return out
+
+
 def arm_block(variant, ids, vals, sd, alpha, n_iter=50, threads=None):
     """Fused block a2..a9 (eval) in one OpenMP call; vals clamped IN PLACE.  Returns [B, O, E]."""
     if threads:

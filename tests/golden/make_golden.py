@@ -315,6 +315,7 @@ def main():
     b64_cases()
     wide_cases()
     big_batch_grad_cases()
+    sibling_cases()
 
 
 def run_sh_cases():
@@ -408,6 +409,72 @@ def big_batch_grad_cases():
     grad_case("h3_grad_1h_a1.0_train_b2304", "1h", base(10, 128, 10, 1.0, 16, mlp_nhid=16), 2304, 144, True)
 
 
+def _sibling_case(name, kind, ctor, B, seed, regime):
+    """S1/S2 - the sibling models SURVEY.md §8f-4 names, eval mode: GC_ARMModel (models/gc_arm.py) and AFNModel
+    (models/afn.py).  Captured: the BatchNorm'd block output (x_arm slot), the logits, the clamped values and, for AFN,
+    the embedding table after embedding_clip (afn.py:74-77 mutates the parameter)."""
+    from models.afn import AFNModel
+    from models.gc_arm import GC_ARMModel
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    if kind == "gc":
+        m = GC_ARMModel(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhead"], ctor["alpha"], ctor["nhid"],
+                        ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"], ctor["deep_nlayer"],
+                        ctor["deep_nhid"])
+        block_bn = m.arm_bn
+    else:
+        m = AFNModel(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhid"], ctor["mlp_nlayer"], ctor["mlp_nhid"],
+                     ctor["dropout"], ctor["ensemble"], ctor["deep_nlayer"], ctor["deep_nhid"])
+        block_bn = m.afn_bn
+    if regime == "stress":
+        with torch.no_grad():
+            w = m.embedding.embedding.weight
+            w.copy_(torch.randn(w.shape, generator=gen) * 0.5)          # AFN: negative entries exercise the clip
+            if kind == "gc":
+                m.attn_layers.Q.mul_(4.0)
+            for bn in [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm1d)]:
+                if bn is block_bn or bn is m.emb_bn:
+                    bn.running_mean.copy_(torch.rand(bn.running_mean.shape, generator=gen) + 0.5)
+                    bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=gen) * 1.5 + 0.5)
+                else:
+                    bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=gen) * 0.05)
+                    bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=gen) * 0.4 + 0.8)
+                bn.weight.copy_(torch.rand(bn.weight.shape, generator=gen) + 0.5)
+                bn.bias.copy_(torch.randn(bn.bias.shape, generator=gen) * 0.1)
+            if hasattr(m, "deep_embedding"):
+                w = m.deep_embedding.embedding.weight
+                w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
+    ids, vals = _inputs(B, ctor["nfield"], ctor["nfeat"], gen)
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    cap = {}
+    h = block_bn.register_forward_hook(lambda mod, i, o: cap.__setitem__("x_arm", o.detach().clone()))
+    x = {"id": ids.clone(), "value": vals.clone(), "y": torch.zeros(B)}
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+    h.remove()
+    cap["logits"] = y.detach().clone()
+    cap["vals_clamped"] = x["value"].detach().clone()
+    if kind == "afn":
+        cap["table_after"] = m.embedding.embedding.weight.detach().clone()
+    meta = dict(name=name, variant=kind, ctor=ctor, regime=regime, seed=seed, train=False, torch=torch.__version__)
+    _save(name, meta, sd_before, ids, vals, cap)
+
+
+def sibling_cases():
+    for alpha in (1.0, 1.7, 2.0):
+        _sibling_case(f"s1_gcarm_criteo_k2_a{alpha}_stress", "gc", base(39, 512, 16, alpha, 16, nhead=2), 16, 151, "stress")
+    _sibling_case("s1_gcarm_frappe_k4_a1.5_ens_stress", "gc",
+                  base(10, 400, 10, 1.5, 8, nhead=4, ensemble=True, mlp_nhid=16, deep_nhid=16), 17, 152, "stress")
+    _sibling_case("s1_gcarm_avazu_k1_a2.0_fresh", "gc", base(22, 400, 32, 2.0, 32, nhead=1), 9, 153, "fresh")
+    _sibling_case("s1_gcarm_odd_k3_f7_e8_h5_a2.5", "gc", base(7, 300, 8, 2.5, 5, nhead=3, mlp_nlayer=1), 11, 154, "stress")
+    _sibling_case("s2_afn_criteo_h32_stress", "afn", base(39, 512, 16, 1.0, 32), 16, 161, "stress")
+    _sibling_case("s2_afn_frappe_h10_ens_stress", "afn",
+                  base(10, 400, 10, 1.0, 10, ensemble=True, mlp_nhid=16, deep_nhid=16), 17, 162, "stress")
+    _sibling_case("s2_afn_avazu_h64_e32_fresh", "afn", base(22, 400, 32, 1.0, 64), 9, 163, "fresh")
+    _sibling_case("s2_afn_odd_f7_e5_h600", "afn", base(7, 300, 5, 1.0, 600, mlp_nlayer=1, mlp_nhid=8), 5, 164, "stress")
+
+
 def entmax_grad_cases():
     """G6b: backward of the sparse map alone (utils/entmax.py:70-80), dX for a random dY."""
     from utils.entmax import entmax_bisect
@@ -432,7 +499,9 @@ def entmax_grad_cases():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--round2-only":      # add the round-2 cases without rewriting the others
+    if len(sys.argv) > 1 and sys.argv[1] == "--siblings-only":
+        sibling_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round2-only":      # add the round-2 cases without rewriting the others
         b64_cases()
         wide_cases()
         big_batch_grad_cases()

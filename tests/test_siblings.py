@@ -1,0 +1,121 @@
+"""GC-ARM and AFN on the fused kernels: golden vectors captured from the reference's
+models/gc_arm.py and models/afn.py (tests/golden/s1_*, s2_*), the CPU oracle's restatement held to them, and the HIP
+path (armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head) held to both."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN, load
+from oracle import armnet_oracle as orc
+from tol_util import TOL, assert_close, elem_excess, rel_err
+
+DEV = "cuda:0"
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s[12]_*.npz")))
+
+
+def _build(meta, sd=None, device=None):
+    c = meta["ctor"]
+    if meta["variant"] == "gc":
+        from models.gc_arm import GC_ARMModel
+        m = GC_ARMModel(c["nfield"], c["nfeat"], c["nemb"], c["nhead"], c["alpha"], c["nhid"], c["mlp_nlayer"],
+                        c["mlp_nhid"], c["dropout"], c["ensemble"], c["deep_nlayer"], c["deep_nhid"])
+    else:
+        from models.afn import AFNModel
+        m = AFNModel(c["nfield"], c["nfeat"], c["nemb"], c["nhid"], c["mlp_nlayer"], c["mlp_nhid"], c["dropout"],
+                     c["ensemble"], c["deep_nlayer"], c["deep_nhid"])
+    if sd is not None:
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    return m.to(device) if device is not None else m
+
+
+def _oracle(meta, sd, ids, vals):
+    return (orc.forward_gc_arm if meta["variant"] == "gc" else orc.forward_afn)(meta["ctor"], sd, ids, vals)
+
+
+def test_fixture_families_are_present():
+    assert sum(n.startswith("s1_") for n in CASES) >= 5 and sum(n.startswith("s2_") for n in CASES) >= 4
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(name):
+    meta, sd, ids, vals, ref = load(name)
+    got = _oracle(meta, sd, ids, vals)
+    np.testing.assert_array_equal(got["vals_clamped"], ref["vals_clamped"])
+    assert_close(got["x_arm"], ref["x_arm"], TOL, name + " block")
+    # logits: bar relative to the head's input magnitude (AFN's exp(Linear(log x)) reaches 1e2..1e3)
+    scale = max(1.0, float(np.max(np.abs(ref["x_arm"]))))
+    assert rel_err(got["logits"], ref["logits"]) <= TOL * scale, name
+    if "table_after" in ref:
+        np.testing.assert_array_equal(got["table_after"], ref["table_after"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_module_has_the_reference_state_dict(name):
+    """same keys in the same order as the reference module that produced the fixture (strict load both ways)"""
+    meta, sd, _, _, _ = load(name)
+    m = _build(meta, sd)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+
+
+def test_training_mode_is_refused_loudly():
+    meta, sd, ids, vals, _ = load("s2_afn_frappe_h10_ens_stress")
+    m = _build(meta, sd)
+    m.train()
+    with pytest.raises((NotImplementedError, Exception)):
+        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_forward_matches_reference(name):
+    meta, sd, ids, vals, ref = load(name)
+    m = _build(meta, sd, DEV)
+    x = {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+    with torch.no_grad():
+        y = m(x)
+        if meta["variant"] == "gc":
+            block = m.arm_block(x["id"], x["value"].clone())
+        else:
+            block = m.afn_block(x["id"], x["value"].clone())
+    assert tuple(y.shape) == ref["logits"].shape
+    np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])      # in-place clamp
+    assert_close(block.cpu().numpy(), ref["x_arm"], TOL, name + " block")
+    scale = max(1.0, float(np.max(np.abs(ref["x_arm"]))))
+    assert rel_err(y.cpu().numpy(), ref["logits"]) <= TOL * scale
+    if "table_after" in ref:                                                           # embedding_clip side effect
+        np.testing.assert_array_equal(m.embedding.embedding.weight.detach().cpu().numpy(), ref["table_after"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s1_gcarm_criteo_k2_a1.7_stress", "s1_gcarm_frappe_k4_a1.5_ens_stress",
+                                  "s2_afn_criteo_h32_stress", "s2_afn_odd_f7_e5_h600"])
+def test_hip_block_matches_oracle_on_a_larger_batch(name):
+    meta, sd, _, _, _ = load(name)
+    c = meta["ctor"]
+    g = torch.Generator().manual_seed(17)
+    B = 1000 + 37
+    ids = torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g)
+    vals = torch.rand(B, c["nfield"], generator=g) * 1.2 - 0.1
+    m = _build(meta, sd, DEV)
+    with torch.no_grad():
+        y = m({"id": ids.to(DEV), "value": vals.clone().to(DEV)})
+        block = (m.arm_block if meta["variant"] == "gc" else m.afn_block)(ids.to(DEV), vals.clone().to(DEV))
+    want = _oracle(meta, sd, ids.numpy(), vals.numpy())
+    assert_close(block.cpu().numpy(), want["x_arm"], TOL, name)
+    scale = max(1.0, float(np.max(np.abs(want["x_arm"]))))
+    assert rel_err(y.cpu().numpy(), want["logits"]) <= TOL * scale
+
+
+@pytest.mark.gpu
+def test_out_of_range_id_raises_indexerror_for_the_siblings():
+    for name in ("s1_gcarm_criteo_k2_a2.0_stress", "s2_afn_criteo_h32_stress"):
+        meta, sd, ids, vals, _ = load(name)
+        m = _build(meta, sd, DEV)
+        bad = ids.copy()
+        bad[2, 5] = meta["ctor"]["nfeat"]
+        with pytest.raises(IndexError), torch.no_grad():
+            m({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
