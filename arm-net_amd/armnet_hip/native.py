@@ -30,7 +30,7 @@ EXPORTS = (
     "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
     "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
-    "armnet_abs_clamp_min_f32",
+    "armnet_abs_clamp_min_f32", "armnet_shard_pad_route",
 )
 
 _lib = None
@@ -414,3 +414,11 @@ def abs_clamp_min(t, lo):
     _dev_f32(t, "t")
     with _on(t):
         check(load().armnet_abs_clamp_min_f32(_ptr(t), ctypes.c_int64(t.numel()), ctypes.c_float(lo), _stream()))
+
+
+def shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow):
+    _i32_ok(counts=counts, send_local=send_local, perm=perm, send_pad=send_pad, perm_pad=perm_pad, overflow=overflow)
+    with _on(counts, send_local, perm, send_pad, perm_pad, overflow):
+        check(load().armnet_shard_pad_route(ctypes.c_int64(n), int(R), ctypes.c_int64(cap), _ptr(counts),
+                                            _ptr(send_local), _ptr(perm), _ptr(send_pad), _ptr(perm_pad),
+                                            _ptr(overflow), _stream()))

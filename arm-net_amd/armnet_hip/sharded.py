@@ -1,14 +1,25 @@
 """Row-sharded embedding lookup over RCCL (no reference counterpart — SURVEY.md §8e).
 
 Rank r of R owns the table rows ``{i : i % R == r}`` (local index ``i // R``; the modulo partition
-balances skewed ids).  One lookup of a rank's ``ids [B, F]``:
+balances skewed ids).  One lookup of a rank's ``ids [B, F]``, default protocol ("fixed": no host synchronisation
+anywhere in the step):
 
     route      armnet_shard_route_ids: counting sort of the B*F ids by owner          (HIP, this rank)
-    exchange   all_gather of the R counts  ->  every rank knows the R x R split matrix (tiny)
-    exchange   all_to_all_single of int32 local row indices                             (RCCL over xGMI)
+    pad        armnet_shard_pad_route: R equal slots of `cap` indices (cap ~ 1.25 n/R) (HIP, this rank)
+    exchange   all_to_all_single, EQUAL splits, of int32 local row indices              (RCCL over xGMI)
     gather     armnet_gather_scale_f32(vals=NULL): owner reads its rows                 (HIP, HBM-bound)
-    exchange   all_to_all_single of the rows (E*4 bytes per DISTINCT id with de-dup)    (RCCL over xGMI)
-    consume    armnet_fused_fwd_f32 with table = received rows, ids = perm (int32)      (no un-permute pass)
+    exchange   all_to_all_single, EQUAL splits, of the rows (E*4 bytes per slot entry)  (RCCL over xGMI)
+    consume    armnet_fused_fwd_f32 with table = received rows, ids = perm_pad (int32)  (no un-permute pass)
+
+The split sizes are known to the host without looking at the data, so routing, both exchanges, the gather and the
+fused kernel are enqueued back to back (and micro-batches really overlap).  The price is the slack of the slots
+(25 % more exchanged bytes; none with de-duplication, whose slot is the owner's whole shard at most).  A slot that
+overflows sets a device flag; `overflowed()` reduces it over the ranks — the one place that synchronises, called by
+`sharded_arm_block` only when the caller asked for checked execution — and the step is then repeated with the
+"exact" protocol, which exchanges exactly counts[r] entries per peer and pays one host synchronisation for it:
+
+    exchange   all_gather of the R counts  ->  every rank knows the R x R split matrix (tiny, then .cpu())
+    exchange   all_to_all_single of int32 local row indices / of the rows, data-dependent splits
 
 The arithmetic of the fused block is untouched: the sharded result is bit-equal to the single-GPU one.
 `ops` abstracts the two device kernels so that the routing logic can be exercised by world_size-2
@@ -50,6 +61,15 @@ class HipShardOps:
             native.gather_scale(local_idx.numel(), table_local.shape[1], local_idx, None, table_local, out)
         return out
 
+    def pad_route(self, counts, send_local, perm, R, cap, overflow):
+        """-> send_pad [R*cap], perm_pad [n] (armnet_shard_pad_route); overflow (int32[1]) |= 1 if a slot is too small"""
+        n = perm.numel()
+        dev = counts.device
+        send_pad = torch.empty(R * cap, device=dev, dtype=torch.int32)
+        perm_pad = torch.empty(n, device=dev, dtype=torch.int32)
+        native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
+        return send_pad, perm_pad
+
 
 def shard_rows(full_table, rank, world):
     """Local shard of a full [nfeat, E] table under the modulo partition."""
@@ -59,7 +79,10 @@ def shard_rows(full_table, rank, world):
 class RowShardedTable:
     """One rank's shard of the embedding table + the lookup protocol above."""
 
-    def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto"):
+    def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto", protocol="fixed", capacity_factor=1.25):
+        self.protocol = protocol  # "fixed": equal-split exchanges, no host sync | "exact": data-dependent splits
+        self.capacity_factor = float(capacity_factor)
+        self._overflow = None     # device flag of the fixed protocol, OR-ed by every lookup since the last check
         self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
         self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
         self.table_local = table_local
@@ -75,9 +98,74 @@ class RowShardedTable:
         if table_local.shape[0] != expect:
             raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
 
-    def lookup(self, ids, id_status=None):
-        """ids [B, F] (this rank's samples) -> (rows [B*F, E] in send order, perm [B*F] int32).
+    def capacity(self, n, dedup):
+        """slot size of the fixed protocol for n lookups: the mean n/R plus the slack factor and a few standard
+        deviations for small batches; with de-duplication never more than the owner's shard"""
+        R = self.world
+        cap = int(self.capacity_factor * n / R) + 4 * int((n / R) ** 0.5) + 16
+        cap = min(cap, max(n, 1))
+        if dedup:
+            cap = min(cap, (self.nfeat + R - 1) // R)
+        return max(cap, 1)
+
+    def overflowed(self):
+        """True on every rank if a slot of the fixed protocol overflowed on ANY rank since the last call (one tiny
+        all-reduce + the host read: the only synchronisation of that protocol); resets the flag."""
+        if self._overflow is None:
+            return False
+        flag = self._overflow
+        if dist.is_initialized() and self.world > 1:
+            if self._via_host:
+                h = flag.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                hit = bool(h.item())
+            else:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                hit = bool(flag.item())
+        else:
+            hit = bool(flag.item())
+        flag.zero_()
+        return hit
+
+    def lookup(self, ids, id_status=None, protocol=None):
+        """ids [B, F] (this rank's samples) -> (rows, perm int32 [B*F]) with rows[perm[i]] = table[ids[i]].
         id_status: optional int32[1] device flag, set when an id is out of range (the caller raises IndexError)."""
+        if (protocol or self.protocol) == "fixed":
+            return self._lookup_fixed(ids, id_status)
+        return self._lookup_exact(ids, id_status)
+
+    def _lookup_fixed(self, ids, id_status=None):
+        R = self.world
+        flat = ids.reshape(-1).contiguous()
+        n = flat.numel()
+        dev = flat.device
+        dedup = (8 * n >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
+        if self._overflow is None or self._overflow.device != dev:
+            self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+        if n == 0:                                     # an empty slice still takes part in the exchanges
+            counts = torch.zeros(R, device=dev, dtype=torch.int32)
+            send_local = torch.zeros(1, device=dev, dtype=torch.int32)
+            perm = torch.empty(0, device=dev, dtype=torch.int32)
+        elif id_status is not None:
+            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
+        else:
+            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
+        # every rank must use the same slot size: it is a function of the batch shape only, so the ranks must hand in
+        # equally shaped batches per step (data-parallel inference with padded / dropped last batches), or fix the
+        # size for good with `slot_lookups`
+        cap = self.capacity(int(getattr(self, "slot_lookups", None) or max(n, 1)), dedup)
+        send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
+        E = self.table_local.shape[1]
+        if R == 1 and not dist.is_initialized():
+            return self.ops.gather(send_pad, self.table_local), perm_pad
+        recv_idx = torch.empty(R * cap, device=dev, dtype=torch.int32)
+        self._all_to_all(recv_idx, send_pad, None, None)
+        rows_out = self.ops.gather(recv_idx, self.table_local)
+        rows_in = torch.empty(R * cap, E, device=dev, dtype=torch.float32)
+        self._all_to_all(rows_in, rows_out, None, None)
+        return rows_in, perm_pad
+
+    def _lookup_exact(self, ids, id_status=None):
         R = self.world
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
@@ -112,6 +200,7 @@ class RowShardedTable:
         return rows_in, perm
 
     def _all_to_all(self, out, inp, out_splits, in_splits):
+        """out_splits / in_splits None = equal splits"""
         if self._via_host:
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(h, inp.cpu(), out_splits, in_splits, group=self.group)
@@ -121,22 +210,32 @@ class RowShardedTable:
 
 
 def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
-                      write_clamped_vals=True, flags=0, micro_batches=None, check_ids=False):
+                      write_clamped_vals=True, flags=0, micro_batches=None, check_ids=False, verify=None):
     """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E].
 
     With micro_batches > 1 the batch is processed in slices whose lookups (routing, the two exchanges, the owner-side
     gather) run on a side stream, so the exchange of slice m+1 overlaps the fused kernel of slice m.  Every rank must
     use the same number of slices (the collectives pair up slice by slice).  Default: `shard.micro_batches` (1).
     With check_ids an out-of-range id raises IndexError like the replicated path (one host sync at the end of the call;
-    the routing kernels flag it, the lookup itself reads row 0 for such an id)."""
+    the routing kernels flag it, the lookup itself reads row 0 for such an id).
+    verify (default: check_ids; must be the same on every rank): after the step is enqueued, ask `shard.overflowed()`
+    whether a slot of the fixed-capacity protocol was too small anywhere and, if so, redo the step with the exact
+    protocol.  Unverified callers (benchmarks, serving loops that batch the check) call `shard.overflowed()` themselves."""
     from .block import arm_block_forward
     B, F = vals.shape
     M = int(micro_batches if micro_batches is not None else getattr(shard, "micro_batches", 1))
     status = torch.zeros(1, device=ids.device, dtype=torch.int32) if (check_ids and ids.is_cuda) else None
+    verify = check_ids if verify is None else verify
+    vals_in = vals.clone() if (verify and getattr(shard, "protocol", "exact") == "fixed") else None
 
     def finish(out):
         if status is not None and int(status.item()) != 0:
             raise IndexError("index out of range in self")
+        if vals_in is not None and shard.overflowed():
+            vals.copy_(vals_in)                     # the clamp is idempotent, but start from the caller's values
+            rows, perm = shard.lookup(ids, None, protocol="exact")
+            return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
+                                     n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags)
         return out
 
     if M <= 1 or not vals.is_cuda:

@@ -63,6 +63,10 @@ def parse():
                     help="replicate = every rank holds the table (no collective); rows = table row-sharded over "
                          "the ranks, RCCL all-to-all lookup (SURVEY §8e); both (default when N > 1) = value from "
                          "replicate plus a row_sharded object measured in the same run")
+    ap.add_argument("--dedup", choices=["auto", "on", "off"], default="auto",
+                    help="row-sharded variant: per-rank id de-duplication before the exchange")
+    ap.add_argument("--protocol", choices=["fixed", "exact"], default="fixed",
+                    help="row-sharded variant: fixed-capacity equal-split exchanges (no host sync) or exact splits")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="row-sharded variant: slices per step whose exchanges overlap the previous slice's kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +103,8 @@ def build_model(a, device, rank=0, world=1, regime=None):
         bound = (6.0 / (a.nfeat + a.nemb)) ** 0.5 if regime == "fresh" else 0.87    # xavier-uniform / stress
         gdev = torch.Generator(device=device).manual_seed(2025 + rank)
         shard = (torch.rand(n_local, a.nemb, device=device, generator=gdev) * 2 - 1) * bound
-        m._shard = RowShardedTable(shard, a.nfeat, None)
+        m._shard = RowShardedTable(shard, a.nfeat, None, protocol=a.protocol,
+                                   dedup={"auto": "auto", "on": True, "off": False}[a.dedup])
         m._shard.micro_batches = a.micro_batches
         m.nfeat = a.nfeat
     return m
@@ -270,6 +275,7 @@ def main():
     head = regimes[0]                                     # `value` regime: fresh (random-init weights) unless --regime
     model = models[head]
     wall_ms, ev_ms, full_wall_ms = res[head]
+    sharded_overflow = None
 
     # Row-sharded variant: same model, same batches, the table row-sharded over the ranks and fetched by all-to-all.
     # It runs AFTER the headline numbers are final and under a watchdog: whatever happens in there (an exception on
@@ -283,6 +289,8 @@ def main():
                 torch.cuda.set_device(local)
                 model.shard_embedding()
                 model._shard.micro_batches = a.micro_batches
+                model._shard.protocol = a.protocol
+                model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
                 turn = [0]
 
                 def step_sharded():
@@ -298,6 +306,9 @@ def main():
                 if use_dist:
                     dist.all_reduce(ts, op=dist.ReduceOp.MAX)
                 sharded["ms"] = float(ts.item())
+                # the fixed-capacity protocol never looked at a count on the host: check its overflow flag ONCE, after
+                # the timed steps (a set flag means some lookups read a wrong row: the number would be void)
+                sharded["overflow"] = bool(model._shard.overflowed())
             except Exception as e:  # noqa: BLE001
                 sharded["err"] = f"{type(e).__name__}: {e}"
             sharded["done"] = True
@@ -309,7 +320,11 @@ def main():
             sharded["err"] = "timeout: the row-sharded measurement did not complete (collective hang?)"
     sharded_ms, sharded_err = sharded["ms"], sharded["err"]
     if sharded_err is None and a.shard == "both":
+        if sharded.get("overflow"):
+            sharded_err = "a slot of the fixed-capacity exchange overflowed during the timed steps"
         model._shard = None
+    elif a.shard == "rows":
+        sharded_overflow = bool(model._shard.overflowed())
 
     if rank == 0:
         read_b = a.nfield * (8 + 4 + 4 * a.nemb)          # ids int64 + vals + F rows      
@@ -346,6 +361,16 @@ def main():
 
         ms_per_step = wall_ms / a.steps
         value = world * a.batch * a.steps / (wall_ms * 1e-3)
+        replicated_value, replicated_ms = value, ms_per_step
+        parallelism = (f"dp{world} (table replicated, no collective)" if a.shard != "rows" else
+                       f"dp{world} x row-sharded table (mod {world}), RCCL all-to-all lookup")
+        if a.shard == "both" and sharded_err is None:
+            # N > 1: the headline is the row-sharded table north_star asks for; the replicated-table number (what 288 GB
+            # of HBM per GPU makes possible for every BASELINE.json table) is reported beside it
+            value = world * a.batch * a.steps / (sharded_ms * 1e-3)
+            ms_per_step = sharded_ms / a.steps
+            parallelism = (f"dp{world} x embedding table row-sharded over the {world} ranks (row i on rank i mod {world}), "
+                           f"RCCL all-to-all lookup per step; `replicated` = the same step with the table on every rank")
         ws_mb = NB * (a.batch * a.nfield * 12 + a.batch * O * a.nemb * 4) / 1e6
         line = {
             "metric": "samples/sec, ARM-Net forward (fused embedding + ARM interaction block), "
@@ -359,26 +384,31 @@ def main():
                                    f"(random-init), eval mode; steps rotate over {NB} distinct batches "
                                    f"(ids+vals+out = {ws_mb:.0f} MB per rotation > 256 MiB Infinity Cache; only "
                                    f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read)",
-                       "global_batch": world * a.batch,
-                       "parallelism": (f"dp{world} (table replicated, no collective)" if a.shard != "rows" else
-                                       f"dp{world} x row-sharded table (mod {world}), RCCL all-to-all lookup")},
+                       "global_batch": world * a.batch, "parallelism": parallelism},
             "roofline": roof(head),
             "regimes": {r: regime_obj(r) for r in regimes},
             "full_forward": {"value": world * a.batch * a.steps / (full_wall_ms * 1e-3), "unit": "samples/s",
                              "ms_per_step": full_wall_ms / a.steps,
                              "note": f"fused block + MLP head 2x256 to logits ({model.mlp.eval_path()})"},
         }
+        if a.shard == "both":
+            line["replicated"] = {"value": replicated_value, "unit": "samples/s", "ms_per_step": replicated_ms,
+                                  "note": "table on every rank, batch split, no data-path collective"}
         if a.shard == "both" and sharded_err is not None:
-            line["row_sharded"] = {"error": sharded_err}
+            line["row_sharded"] = {"error": sharded_err,
+                                   "note": "`value` falls back to the replicated-table number for this line"}
         elif a.shard == "both":
             line["row_sharded"] = {
                 "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
                 "ms_per_step": sharded_ms / a.steps,
-                "note": f"same block with the table row-sharded (row i on rank i mod {world}): HIP routing with per-rank "
-                        f"id de-duplication (direct-address mark + scan), all_to_all_single of int32 row indices, "
-                        f"owner-side gather, all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
+                "note": f"(= `value`) the block with the table row-sharded (row i on rank i mod {world}), no host "
+                        f"synchronisation in the step: HIP routing with per-rank id de-duplication (direct-address mark + "
+                        f"scan), fixed-capacity slots, equal-split all_to_all_single of int32 row indices, owner-side "
+                        f"gather, equal-split all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
                         f"{a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB per rank per step, {(world - 1) / world:.0%} of it "
-                        f"across xGMI), fused kernel over (rows, perm)"}
+                        f"across xGMI), fused kernel over (rows, perm); overflow flag checked after the timed steps"}
+        if a.shard == "rows":
+            line["row_sharded_overflow"] = sharded_overflow
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             a_head = argparse.Namespace(**vars(a))
             line["cpu_baseline"] = cpu_baseline(a_head, model, ids_cpu, vals_cpu)

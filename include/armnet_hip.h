@@ -231,6 +231,16 @@ int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R
                                   void* workspace, int64_t ws_bytes, int32_t* id_status, void* stream);
 
 /*
+ * Fixed-capacity layout of a routed lookup: R equal slots of `cap` indices instead of back-to-back owner segments, so
+ * that both exchanges of the row-sharded lookup are EQUAL-SPLIT all-to-alls and no count has to reach the host
+ * (csrc/shard_pad.hip).  counts / send_local / perm as produced by armnet_shard_route_ids or _unique_ids;
+ * send_pad [R*cap], perm_pad [n]; *overflow |= 1 when an owner's count exceeds cap (the caller repeats that step with
+ * the exact, host-synchronised protocol).  Unused slot entries hold local index 0.
+ */
+int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts, const int32_t* send_local,
+                           const int32_t* perm, int32_t* send_pad, int32_t* perm_pad, int32_t* overflow, void* stream);
+
+/*
  * Sibling models on the same kernels, eval mode.
  *
  * armnet_gc_fused_fwd_f32 — models/gc_arm.py:82-95 (GC_ARMModel.forward up to arm_bn):

@@ -514,3 +514,28 @@ def test_hip_abi_against_its_cpu_twin_on_identical_arguments(name):
                      t(sd["embedding.embedding.weight"]), qf, t(sd["attn_layer.values"]).reshape(O, F).contiguous(), sc, sh, out)
     assert status == 0 and _rel_err(out.cpu().numpy(), want) <= TOL
     np.testing.assert_array_equal(v_g.cpu().numpy(), v_c)
+
+
+@pytest.mark.parametrize("R,dedup,cap_factor", [(1, False, 1.25), (2, False, 1.25), (8, False, 1.25), (8, True, 1.25),
+                                                (4, False, 0.5)])
+def test_shard_pad_route_kernel_contract(R, dedup, cap_factor):
+    """armnet_shard_pad_route: R equal slots; rows gathered through (send_pad, perm_pad) reproduce table[ids]; the
+    overflow flag is raised exactly when an owner's count exceeds the slot"""
+    from armnet_hip.sharded import HipShardOps
+    nfeat, n = 50021, 39 * 641
+    ids = torch.randint(0, nfeat, (n,), generator=torch.Generator().manual_seed(R))
+    ops = HipShardOps()
+    counts, send_local, perm = ops.route(ids.to(DEV), R, nfeat, dedup=dedup)
+    cap = int(cap_factor * n / R) + 16
+    overflow = torch.zeros(1, device=DEV, dtype=torch.int32)
+    send_pad, perm_pad = ops.pad_route(counts, send_local, perm, R, cap, overflow)
+    c = counts.cpu().numpy()
+    assert int(overflow.item()) == int((c > cap).any())
+    assert send_pad.numel() == R * cap
+    sp, pp, idn = send_pad.cpu().numpy(), perm_pad.cpu().numpy(), ids.numpy()
+    if not (c > cap).any():
+        owner = pp // cap
+        np.testing.assert_array_equal(owner, idn % R)                  # the slot belongs to the id's owner
+        np.testing.assert_array_equal(sp[pp], idn // R)                # and holds its local row index
+        for o in range(R):                                             # unused entries: index 0
+            assert (sp[o * cap + c[o]: (o + 1) * cap] == 0).all()

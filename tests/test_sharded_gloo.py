@@ -38,8 +38,25 @@ class NumpyShardOps:
     def gather(self, local_idx, table_local):
         return table_local[local_idx.long()].contiguous()
 
+    def pad_route(self, counts, send_local, perm, R, cap, overflow):
+        """contract of armnet_shard_pad_route: R equal slots of cap indices, index 0 in the unused entries"""
+        c = counts.numpy().astype(np.int64)
+        start = np.concatenate([[0], np.cumsum(c)])
+        send_pad = np.zeros(R * cap, np.int32)
+        for o in range(R):
+            k = min(int(c[o]), cap)
+            send_pad[o * cap: o * cap + k] = send_local.numpy()[start[o]: start[o] + k]
+        p = perm.numpy().astype(np.int64)
+        owner = np.searchsorted(start[1:], p, side="right")
+        owner = np.minimum(owner, R - 1)
+        slot = p - start[owner]
+        if (c > cap).any():
+            overflow |= 1
+        perm_pad = (owner * cap + np.where(slot < cap, slot, 0)).astype(np.int32)
+        return torch.from_numpy(send_pad), torch.from_numpy(perm_pad)
 
-def _worker(rank, world, port, nfeat, E, B, F, q, dedup=False):
+
+def _worker(rank, world, port, nfeat, E, B, F, q, dedup=False, protocol="exact", capacity_factor=1.25):
     sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -52,11 +69,16 @@ def _worker(rank, world, port, nfeat, E, B, F, q, dedup=False):
         ids = torch.randint(0, nfeat, (B, F), generator=g2)
         ids[0, :3] = torch.tensor([0, nfeat - 1, 1])                     # boundary rows, both owners
         ids[1, :] = ids[1, 0]                                            # duplicates in one sample
-        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=dedup)
+        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=dedup,
+                                protocol=protocol, capacity_factor=capacity_factor)
         rows, perm = shard.lookup(ids)
         got = rows[perm.long()].view(B, F, E)
         ok = bool(torch.equal(got, table[ids]))
-        q.put((rank, ok, int(rows.shape[0])))
+        over = shard.overflowed() if protocol == "fixed" else False
+        if over:                                       # what sharded_arm_block does: redo with the exact protocol
+            rows2, perm2 = shard.lookup(ids, protocol="exact")
+            ok = bool(torch.equal(rows2[perm2.long()].view(B, F, E), table[ids]))
+        q.put((rank, ok, int(rows.shape[0]), over))
     finally:
         dist.destroy_process_group()
 
@@ -75,6 +97,69 @@ def test_sharded_lookup_protocol_gloo(world, dedup):
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert [r[1] for r in res] == [True] * world, res
     assert all((r[2] == 37 * 5) if not dedup else (r[2] <= 37 * 5) for r in res)
+
+
+def _run(world, port, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port) + args[:4] + (q,) + args[4:]) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(q.get(timeout=5) for _ in range(world))
+
+
+@pytest.mark.parametrize("world,dedup", [(2, False), (3, False), (2, True)])
+def test_fixed_capacity_protocol_without_host_sync_gloo(world, dedup):
+    """the no-sync protocol: equal-split exchanges of padded slots; rows[perm_pad] reproduces table[ids] on every rank,
+    the received buffer has world * cap rows on every rank, nothing overflows at the default slack"""
+    port = 31500 + os.getpid() % 2000 + world + (10 if dedup else 0)
+    res = _run(world, port, (1001, 8, 37, 5, dedup, "fixed", 1.25))
+    assert [r[1] for r in res] == [True] * world, res
+    assert len({r[2] for r in res}) == 1 and res[0][2] % world == 0      # equal slots on every rank
+    assert not any(r[3] for r in res)
+
+
+def test_fixed_capacity_overflow_is_flagged_on_every_rank_and_repeated_exactly():
+    """a slot far too small: the device flag is raised, the all-reduce makes every rank see it, the exact protocol
+    then gives the right rows"""
+    port = 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # skewed ids: every id is owned by rank 0 -> its slot overflows whatever the slack
+    procs = [ctx.Process(target=_skew_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(r[1] for r in res) and all(r[2] for r in res), res
+
+
+def _skew_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from armnet_hip.sharded import RowShardedTable, shard_rows
+        nfeat, E, B, F = 1000, 4, 64, 6
+        table = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(7))
+        ids = torch.randint(0, nfeat // 2, (B, F), generator=torch.Generator().manual_seed(rank)) * 2   # all even
+        if rank == 1:
+            ids = ids + 0                                              # rank 1 also only asks rank 0
+        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=False,
+                                protocol="fixed", capacity_factor=1.0)
+        rows, perm = shard.lookup(ids)
+        over = shard.overflowed()
+        rows2, perm2 = shard.lookup(ids, protocol="exact")
+        ok = bool(torch.equal(rows2[perm2.long()].view(B, F, E), table[ids]))
+        q.put((rank, ok, over))
+    finally:
+        dist.destroy_process_group()
 
 
 def test_numpy_double_matches_route_contract():

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dedup, micro, q):
+def _worker(rank, world, port, dedup, micro, q, protocol="exact"):
     for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -27,7 +27,8 @@ def _worker(rank, world, port, dedup, micro, q):
         meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
         c = meta["ctor"]
         g = torch.Generator().manual_seed(50 + rank)
-        B = 333 + 7 * rank                                    # ragged: the ranks hold different batch sizes
+        # exact protocol: ragged (the ranks hold different batch sizes); fixed-capacity protocol: equal shapes
+        B = 333 + 7 * rank if protocol == "exact" else 333
         ids = torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g)
         ids[0, :3] = torch.tensor([0, c["nfeat"] - 1, 1])     # boundary rows, both owners
         ids[1, :] = ids[1, 0]                                 # duplicates in one sample
@@ -37,22 +38,26 @@ def _worker(rank, world, port, dedup, micro, q):
             want = m.arm_block(ids.to(dev), vals.clone().to(dev))
             m.shard_embedding()
             m._shard.dedup = dedup
+            m._shard.protocol = protocol
             m._shard.micro_batches = micro
             assert m._shard.world == world and m._shard._via_host
             got = m.arm_block(ids.to(dev), vals.clone().to(dev))
+            assert not (protocol == "fixed" and m._shard.overflowed())
         q.put((rank, bool(torch.equal(got, want)), float((got - want).abs().max())))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dedup,micro", [(False, 1), (True, 1), (True, 3), (False, 500)])
-def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro):
+@pytest.mark.parametrize("dedup,micro,protocol", [(False, 1, "exact"), (True, 1, "exact"), (True, 3, "exact"),
+                                                  (False, 500, "exact"), (False, 1, "fixed"), (True, 1, "fixed"),
+                                                  (False, 3, "fixed"), (True, 50, "fixed")])
+def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol):
     """micro > 1: the lookups of slice m+1 run on a side stream beside the fused kernel of slice m; 500 slices for
     333 / 340 samples also exercises empty slices (every rank still takes part in every exchange)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29621 + 2 * int(dedup) + (micro > 1) + 4 * (micro > 100)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, micro, q)) for r in range(2)]
+    port = 29621 + 2 * int(dedup) + (micro > 1) + 4 * (micro > 100) + 8 * (protocol == "fixed") + 16 * (micro == 50)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, micro, q, protocol)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
