@@ -49,10 +49,16 @@ inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_s
 }
 
 constexpr int kNewtonMaxIter = 40;
+// Stop once sum(p) - 1 <= tol.  The row is renormalised by sum(p) afterwards (entmax.py:63-64), which cancels the
+// first-order effect of the threshold error: |dp_i| <= tol * |t_i - 1/k| for a support of k.  Measured on MI355X
+// (tools/parity_margin.py, every eval fixture): the worst element sits at 0.45 (alpha <= 2) of the 1e-5 bar with
+// tol = 2e-7 AND with 6e-7 — it is set by the exponent's rounding in the wide-range fixtures, not by the solver —
+// while 6e-7 saves the second evaluation that a few ulps of summation noise otherwise trigger for a whole wave
+// (alpha = 2: 113.5 -> 109.9 us fresh, 160.8 -> 155.6 us stress; alpha = 1.7: 152 -> 143 / 223 -> 214 us).
 #ifndef ARMNET_NEWTON_TOL
-#define ARMNET_NEWTON_TOL 2e-7f
+#define ARMNET_NEWTON_TOL 6e-7f
 #endif
-constexpr float kNewtonTol = ARMNET_NEWTON_TOL;   // stop once sum(p) - 1 <= tol (a few fp32 ulps of 1)
+constexpr float kNewtonTol = ARMNET_NEWTON_TOL;
 
 // compute units of the current device (256 on MI355X), cached per device; 256 if the query fails
 int device_cu_count();
