@@ -157,6 +157,10 @@ struct MlpArgs {
 
 // 8 fp32 -> three packed bf16x8 planes; h + m + l == x exactly (truncating 8-bit slices of the significand)
 __device__ __forceinline__ void split3(const float (&x)[8], u32x4& ph, u32x4& pm, u32x4& pl) {
+#ifdef ARMNET_MLP_NOSPLIT          // developer ablation (compile-time, results are garbage): no bf16 split
+    for (int i = 0; i < 4; ++i) { ph[i] = __float_as_uint(x[i]); pm[i] = __float_as_uint(x[4 + i]); pl[i] = ph[i]; }
+    return;
+#endif
     uint32_t hb[8], mb[8], lb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -191,6 +195,11 @@ struct APlanes { u32x4 h[PAIR], m[PAIR], l[PAIR]; };
 // ("+v"), which orders their consumers behind it.
 __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
     u32x4 v;
+#ifdef ARMNET_MLP_NOREAD           // developer ablation (compile-time, results are garbage): no LDS plane / tile reads
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(addr));
+    v[1] = v[2] = v[3] = addr;
+    return v;
+#endif
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
@@ -304,8 +313,16 @@ __global__ void __launch_bounds__(64 * kWaves, 2) mlp_head_kernel(MlpArgs a) {
     const MlpLayout L = mlp_layout(a.K0, NT, a.n_hidden);
     const int KS1 = L.KS1;
     const int Q = KS1 + (a.n_hidden >= 2 ? NG * NS2 : 0);              // stages of the whole stream
-#ifdef ARMNET_DEV_FLAGS
+    // developer ablations: runtime (ARMNET_DEV_FLAGS + ARMNET_MLP_DBG; the instrumentation itself costs ~50 %) or
+    // compile-time (-DARMNET_MLP_NODMA / NOSYNC / NOREAD / NOSPLIT: clean timings, garbage results)
+#if defined(ARMNET_DEV_FLAGS)
     const bool dbg_nosync = a.dbg & 1, dbg_nox = a.dbg & 2, dbg_noglds = a.dbg & 4;
+#elif defined(ARMNET_MLP_NODMA) && defined(ARMNET_MLP_NOSYNC)
+    constexpr bool dbg_nosync = true, dbg_nox = true, dbg_noglds = true;
+#elif defined(ARMNET_MLP_NODMA)
+    constexpr bool dbg_nosync = false, dbg_nox = true, dbg_noglds = true;
+#elif defined(ARMNET_MLP_NOSYNC)
+    constexpr bool dbg_nosync = true, dbg_nox = false, dbg_noglds = false;
 #else
     constexpr bool dbg_nosync = false, dbg_nox = false, dbg_noglds = false;
 #endif
@@ -354,6 +371,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) mlp_head_kernel(MlpArgs a) {
         for (int i = 0; i < 4; ++i) { x[i] = __uint_as_float(v[0][i]); x[4 + i] = __uint_as_float(v[1][i]); }
     };
 
+#ifdef ARMNET_MLP_SETPRIO
+    if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the younger wave of every SIMD
+#endif
     // ---- prologue -------------------------------------------------------------------------------------------
     // in order: W(0) W(1) X(0) X(1) X(2)
     issue_w(0);
