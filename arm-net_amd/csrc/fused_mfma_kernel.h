@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     }
     const bool any_pad = SPW * npf + 4 * XQ > 0;
     const bool full_rows = (Er == E);                    // 16-byte stores possible
+    const uint32_t lane_out_off = (uint32_t)c * (uint32_t)Er + 4u * (uint32_t)g;   // floats; per-lane part of every store
     const uint32_t F4 = 4u * (uint32_t)F;
 
     // ---- software pipeline -------------------------------------------------------------------------
@@ -645,7 +646,10 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
                     if (b0 + s < Bi) {
-                        float* dst = a.out + ((size_t)(b0 + s) * O_out + 16 * nt + c) * (size_t)Er + 4 * g;
+                        // wave-uniform part of the address on the scalar unit, the lane's part (c, g) a constant offset:
+                        // mixed in one expression the 64-bit multiply ran on the VALU (two quarter-rate v_mul_lo_u32 and
+                        // a v_mad_u64_u32 per sample and pass)
+                        float* dst = a.out + ((size_t)(b0 + s) * O_out + 16 * nt) * (size_t)Er + lane_out_off;
                         const f32x2 ke = {kexp[s], kexp[s]};
 #pragma unroll
                         for (int eb = 0; eb < EB; ++eb) {
