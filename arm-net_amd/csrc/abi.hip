@@ -73,7 +73,7 @@ static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (!a.vals || !a.q_fold || !a.values || !a.bn_scale || !a.bn_shift || !a.out) return ARMNET_ERR_BAD_ARG;
     if (!(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     a.cfg = make_sparse_cfg(alpha, n_iter, a.F, 1, a.flags);
-    if (a.model == MODEL_ARM && !(a.flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(a.F, a.E, a.O)) {
+    if (!(a.flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(a.F, a.E, a.O)) {
         const int rc = launch_fused_mfma(a, (hipStream_t)stream);
         if (rc != ARMNET_ERR_UNSUPPORTED) return rc;
     }

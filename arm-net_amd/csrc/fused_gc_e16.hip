@@ -1,0 +1,18 @@
+// fused_gc_e16.hip — GC-ARM mode of the fused MFMA kernel, padded embedding width 16 (models/gc_arm.py).
+#include "fused_mfma_kernel.h"
+
+namespace armnet {
+
+int launch_gc_e16(const FusedArgs& a, int nq, hipStream_t st) {
+    switch (nq) {
+        case 2: return launch_sibling<16, 2, MODEL_GC_ARM>(a, st);
+        case 4: return launch_sibling<16, 4, MODEL_GC_ARM>(a, st);
+        case 6: return launch_sibling<16, 6, MODEL_GC_ARM>(a, st);
+        case 8: return launch_sibling<16, 8, MODEL_GC_ARM>(a, st);
+        case 10: return launch_sibling<16, 10, MODEL_GC_ARM>(a, st);
+        case 12: return launch_sibling<16, 12, MODEL_GC_ARM>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace armnet

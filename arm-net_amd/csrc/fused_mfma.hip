@@ -5,7 +5,8 @@ namespace armnet {
 
 // nemb 4..64 (any, odd too: 16-byte staging chunks at the rows' natural 4-byte alignment); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
 // LDS of one block for a slice of `o_slice` neurons (same formula as launch_one): 4 wave tiles + the lane-ready
-// parameters of the slice
+// parameters of the slice (the sibling models add a table of < 1 KiB: a shape at the very edge is refused by
+// launch_one and runs on the generic kernel)
 static size_t mfma_lds_bytes(int F, int E, int o_slice) {
     const int nq = (((F + 3) / 4) + 1) & ~1;
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
@@ -48,8 +49,12 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
         s.bn_scale = a.bn_scale + o0;
         s.bn_shift = a.bn_shift + o0;
         s.out = a.out + (size_t)o0 * a.E;
+        if (a.model == MODEL_AFN) s.lin_bias = a.lin_bias + o0;
         int rc;
-        if (a.E <= 16) rc = launch_mfma_e16(s, nq, st);
+        if (a.model == MODEL_AFN) rc = launch_afn(s, a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64, nq, st);
+        else if (a.model == MODEL_GC_ARM)
+            rc = a.E <= 16 ? launch_gc_e16(s, nq, st) : a.E <= 32 ? launch_gc_e32(s, nq, st) : launch_gc_e64(s, nq, st);
+        else if (a.E <= 16) rc = launch_mfma_e16(s, nq, st);
         else if (a.E <= 32) rc = launch_mfma_e32(s, nq, st);
         else rc = launch_mfma_e64(s, nq, st);
         if (rc != ARMNET_OK) return rc;      // a refusal can only happen on the first slice (same shape after it)

@@ -51,6 +51,8 @@ typedef f32x4 f32x4u __attribute__((aligned(4)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr float kLog2e = 1.44269502162933349609375f;
+constexpr float kLn2 = 0.693147182464599609375f;
 
 // t = clamp01(x - tau), two elements per instruction
 __device__ __forceinline__ f32x2 pk_sub_clamp01(f32x2 x, f32x2 tau) {
@@ -110,7 +112,12 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 
 // E = nemb padded to 16/32/64; NQ = quarter-steps per sample (even); SPW samples per wave-group;
 // SRC: 0 = int64 ids, 1 = int32 ids, 2 = pre-gathered rows; WPS = waves/SIMD the register budget targets;
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS>
+// MODEL: MODEL_ARM, or one of the sibling models that share the staging, the tile layout and MFMA #2:
+//   MODEL_GC_ARM  gates += their row sum before the sparse map (gc_arm.py:37-41); MFMA #2 runs on emb_bn(exp(x)) formed
+//                 in registers from the tile (gc_arm.py:89); no outer exp (gc_arm.py:92-94);
+//   MODEL_AFN     the tile holds log2(x); no MFMA #1 and no sparse map: the B operand of MFMA #2 is afn.weight with the
+//                 emb_bn scale folded in, the emb_bn shift goes into the bias (afn.py:63-66).
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM>
 __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
     constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
@@ -141,6 +148,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     float* p_bq = lds_all + 4 * WAVE_FLOATS;               // [NT][EB][64] f32x4
     float* p_vv = p_bq + NT * EB * 64 * 4;                 // [NT][NP][64] f32x2
     float* p_bn = p_vv + NT * NP * 64 * 2;                 // [NT][16] f32x2 {scale, shift}
+    float* p_x = p_bn + NT * 32;                           // GC-ARM: [NQ][4] f32x2 emb_bn {scale, shift} of field 4j+g; AFN: [NT][16] bias * log2(e)
 
     // all group bookkeeping is 32-bit and wave-uniform (SALU): launcher guarantees B*F*8 < 2^32
     const int Bi = (int)a.B;
@@ -282,7 +290,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     };
 
     if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
-    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+    for (int i = threadIdx.x; MODEL != MODEL_AFN && i < NT * EB * 64; i += 256) {
         const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
         const int o = 16 * nt + (l & 15);
         const int e0 = 16 * kb + 4 * (l >> 4);
@@ -299,7 +307,26 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         f32x2 v;
         v[0] = (o < O && f0 < F) ? a.values[(size_t)o * F + f0] : 0.f;
         v[1] = (o < O && f1 < F) ? a.values[(size_t)o * F + f1] : 0.f;
+        if constexpr (MODEL == MODEL_AFN) {
+            // the tile holds log2(x): W[o,f] * (ln(x) * s_f + t_f) = (W[o,f] * s_f * ln2) * log2(x) + W[o,f] * t_f
+            if (f0 < F) v[0] *= a.emb_scale[f0] * kLn2;
+            if (f1 < F) v[1] *= a.emb_scale[f1] * kLn2;
+        }
         *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
+    }
+    if constexpr (MODEL == MODEL_GC_ARM) {
+        for (int i = threadIdx.x; i < NQ * 4; i += 256)      // pad fields: 0 * exp(0) + 0 = 0
+            *reinterpret_cast<f32x2*>(p_x + i * 2) = i < F ? f32x2{a.emb_scale[i], a.emb_shift[i]} : f32x2{0.f, 0.f};
+    }
+    if constexpr (MODEL == MODEL_AFN) {
+        for (int o = threadIdx.x; o < NT * 16; o += 256) {
+            float bsum = 0.f;
+            if (o < O) {
+                bsum = a.lin_bias[o];
+                for (int f = 0; f < F; ++f) bsum = fmaf(a.values[(size_t)o * F + f], a.emb_shift[f], bsum);
+            }
+            p_x[o] = bsum * kLog2e;
+        }
     }
     for (int i = threadIdx.x; i < NT * 16; i += 256)
         *reinterpret_cast<f32x2*>(p_bn + i * 2) = i < O ? f32x2{a.bn_scale[i], a.bn_shift[i]} : f32x2{0.f, 0.f};
@@ -320,7 +347,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
     const float invF = 1.0f / (float)F;
     const float tau_off = a.cfg.tau_hi_off;
-    const float L2E = 1.44269502162933349609375f;
+    const float L2E = kLog2e;
 
     for (; grp < ngroups; grp += nwaves) {
         const int b0 = grp * SPW;
@@ -337,6 +364,12 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             vcl[n] = v;
             changed |= (v != vraw) && !pad[n];
             RowT r = rows_cur[n] * v;
+            if constexpr (MODEL == MODEL_AFN) {
+                // afn.py:63 log(x_emb) as log2 (ln2 is folded into the weights); x > 0 after embedding_clip, a
+                // negative or NaN entry gives NaN as in the reference.  Lanes of the row padding keep zeros.
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = chunk_ok ? __builtin_amdgcn_logf(r[q]) : 0.f;
+            }
             {
                 if (rem != 0) {                                         // kernel-uniform
                     // partial chunk: the lane holds the row's last 4 floats; its own are the last `rem` of them
@@ -369,31 +402,8 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         PHASE(0);
 
         for (int nt = 0; nt < NT; ++nt) {
-            // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
-            f32x4 c1[NTILE];
-#pragma unroll
-            for (int kb = 0; kb < EB; ++kb) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
-                f32x4 av[NTILE];
-#pragma unroll
-                for (int t = 0; t < NTILE; ++t)
-                    av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
-                if (dbg_no_mfma) {
-#pragma unroll
-                    for (int t = 0; t < NTILE; ++t) c1[t] = av[t] * bq;
-                    continue;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int t = 0; t < NTILE; ++t) {
-                        if (kb == 0 && kk == 0)
-                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        else
-                            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
-                    }
-            }
-            PHASE(1);
+            f32x4 c1[NTILE];                  // gates, then the B operand of MFMA #2
+            float kexp[SPW];                  // scale of the contraction's result
             // element j of sample s; pairs (2jp, 2jp+1) are register-pair aligned because NQ is even
 #define XG(s, j) c1[((s) * NQ + (j)) >> 2][((s) * NQ + (j)) & 3]
 #define XP_GET(s, jp) (f32x2{XG(s, 2 * (jp)), XG(s, 2 * (jp) + 1)})
@@ -405,228 +415,275 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     } while (0)
             const float* vv_base = p_vv + (nt * NP * 64 + lane) * 2;
 #define VV(jp) (*reinterpret_cast<const f32x2*>(vv_base + (jp) * 128))
+            if constexpr (MODEL == MODEL_AFN) {
+                // afn.py:64: a plain Linear over the fields: the B operand is the (folded) weight itself
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) XG(s, j) = VV(j >> 1)[j & 1];
+                    kexp[s] = L2E;
+                }
+            } else {
+                // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
+#pragma unroll
+                for (int kb = 0; kb < EB; ++kb) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
+                    f32x4 av[NTILE];
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t)
+                        av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                    if (dbg_no_mfma) {
+#pragma unroll
+                        for (int t = 0; t < NTILE; ++t) c1[t] = av[t] * bq;
+                        continue;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int t = 0; t < NTILE; ++t) {
+                            if (kb == 0 && kk == 0)
+                                c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            else
+                                c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bq[kk], c1[t], 0, 0, 0);
+                        }
+                }
+                PHASE(1);
 
-            // ---- sparse map over the fields ------------------------------------------------------------
-            // On exit XG holds the UNNORMALISED weights p * values and kexp[s] = log2(e) / sum(p).
-            float kexp[SPW];
-            // row sum (for the mean start / NaN detection) and row max, partials to LDS
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                f32x2 sm2;
-#pragma unroll
-                for (int jp = 0; jp < NP; ++jp) {
-                    f32x2 x = XP_GET(s, jp);
-                    if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
-                        x *= f32x2{am1, am1};               // entmax.py:42
-                        XP_SET(s, jp, x);
-                    }
-                    sm2 = jp == 0 ? x : sm2 + x;            // a pad field's gate is exactly 0
-                }
-                XG(s, NQ - 1) += padneg_a;                  // pad fields -> -inf (never in the support)
-                if (two_pad) XG(s, NQ - 2) += padneg_b;     // wave-uniform
-                float mx;
-                if constexpr (NQ == 2) {                    // compiler-visible: first readers of the accumulators
-                    mx = cmax2(XG(s, 0), XG(s, 1));
-                } else {
-                    mx = cmax3(XG(s, 0), XG(s, 1), XG(s, 2));
-#pragma unroll
-                    for (int j = 3; j + 1 < NQ; j += 2) mx = cmax3(mx, XG(s, j), XG(s, j + 1));
-                    mx = cmax2(mx, XG(s, NQ - 1));
-                }
-                red_write(red, s & 1, lane, mx, sm2[0] + sm2[1]);
-            }
-            wave_lds_fence();
-            float tau[SPW], Ssum[SPW];
-            float tau_hi[MODE == SOLVE_BISECT ? SPW : 1];
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                const Red2 r = red_read(red, s & 1, c);
-                const float mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
-                const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
-                if constexpr (MODE == SOLVE_SOFTMAX) {
-                    tau[s] = mx + (sm - sm);                // NaN / inf anywhere -> NaN row
-                } else if constexpr (MODE == SOLVE_BISECT) {
-                    tau[s] = (mx - 1.0f) + (sm - sm);       // tau_lo (entmax.py:46); NaN / inf anywhere -> NaN row
-                    tau_hi[s] = mx - tau_off;               // entmax.py:47
-                } else {
-                    // tau0 = max(mx - 1, mean - d^-(alpha-1)) <= root; NaN/inf gates poison the row
-                    tau[s] = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
-                }
-                Ssum[s] = 1.0f;
-            }
-            PHASE(2);
-            if constexpr (MODE == SOLVE_SOFTMAX) {
+                // ---- sparse map over the fields ------------------------------------------------------------
+                // On exit XG holds the UNNORMALISED weights p * values and kexp[s] = log2(e) / sum(p).
+                // row sum (for the mean start / NaN detection) and row max, partials to LDS
                 wave_lds_fence();
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
-                    float S = 0.f;
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const float p = __builtin_amdgcn_exp2f((XG(s, j) - tau[s]) * L2E);
-                        S += p;
-                        XG(s, j) = p * VV(j >> 1)[j & 1];
-                    }
-                    red_write(red, s & 1, lane, S, 0.f);
-                }
-                wave_lds_fence();
-#pragma unroll
-                for (int s = 0; s < SPW; ++s) {
-                    const Red2 q = red_read(red, s & 1, c);
-                    Ssum[s] = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
-                }
-            } else if constexpr (MODE == SOLVE_BISECT) {
-                // The reference's bisection, statement for statement (utils/entmax.py:49-64), for alpha > 2, n_iter < 24
-                // and ARMNET_F_FAITHFUL_BISECT: f_lo at tau_lo, then n_iter halvings; p is the one of the LAST tau_m.
-                // t^(1/(alpha-1)) through the hardware log2/exp2 pair (2 transcendentals per element and step).
-                f32x2 pkeep[SPW * NP];
-                float f_lo[SPW], dm[SPW];
-                auto eval = [&](int s_, float t_at) -> float {          // p(t_at) into pkeep, partial row sum
-                    const f32x2 tk = {t_at, t_at};
-                    f32x2 S2;
+                    f32x2 sm2;
 #pragma unroll
                     for (int jp = 0; jp < NP; ++jp) {
-                        const f32x2 t = pk_sub_clamp01(XP_GET(s_, jp), tk);     // tau >= max - 1  =>  x - tau <= 1
-                        f32x2 pv;
-                        pv[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));   // log2(0) = -inf -> 0
-                        pv[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
-                        pkeep[s_ * NP + jp] = pv;
-                        S2 = jp == 0 ? pv : S2 + pv;
+                        f32x2 x = XP_GET(s, jp);
+                        if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
+                            x *= f32x2{am1, am1};               // entmax.py:42
+                            XP_SET(s, jp, x);
+                        }
+                        sm2 = jp == 0 ? x : sm2 + x;            // a pad field's gate is exactly 0
                     }
-                    return S2[0] + S2[1];
-                };
-                wave_lds_fence();
+                    XG(s, NQ - 1) += padneg_a;                  // pad fields -> -inf (never in the support)
+                    if (two_pad) XG(s, NQ - 2) += padneg_b;     // wave-uniform
+                    float mx;
+                    if constexpr (NQ == 2) {                    // compiler-visible: first readers of the accumulators
+                        mx = cmax2(XG(s, 0), XG(s, 1));
+                    } else {
+                        mx = cmax3(XG(s, 0), XG(s, 1), XG(s, 2));
 #pragma unroll
-                for (int s = 0; s < SPW; ++s) red_write(red, s & 1, lane, eval(s, tau[s]), 0.f);
+                        for (int j = 3; j + 1 < NQ; j += 2) mx = cmax3(mx, XG(s, j), XG(s, j + 1));
+                        mx = cmax2(mx, XG(s, NQ - 1));
+                    }
+                    red_write(red, s & 1, lane, mx, sm2[0] + sm2[1]);
+                }
                 wave_lds_fence();
+                float tau[SPW], Ssum[SPW];
+                float tau_hi[MODE == SOLVE_BISECT ? SPW : 1];
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
                     const Red2 r = red_read(red, s & 1, c);
-                    Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
-                    f_lo[s] = Ssum[s] - 1.0f;
-                    dm[s] = tau_hi[s] - tau[s];
+                    float mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
+                    float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                    if constexpr (MODEL == MODEL_GC_ARM) {
+                        // gc_arm.py:37-41: the global context is the bilinear form of the field SUM = the sum of the
+                        // gates (already scaled by alpha - 1 here); added to every gate of the row (pads stay -inf)
+                        const float gcx = sm;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) XG(s, j) += gcx;
+                        mx += gcx;
+                        sm = fmaf((float)F, gcx, sm);
+                    }
+                    if constexpr (MODE == SOLVE_SOFTMAX) {
+                        tau[s] = mx + (sm - sm);                // NaN / inf anywhere -> NaN row
+                    } else if constexpr (MODE == SOLVE_BISECT) {
+                        tau[s] = (mx - 1.0f) + (sm - sm);       // tau_lo (entmax.py:46); NaN / inf anywhere -> NaN row
+                        tau_hi[s] = mx - tau_off;               // entmax.py:47
+                    } else {
+                        // tau0 = max(mx - 1, mean - d^-(alpha-1)) <= root; NaN/inf gates poison the row
+                        tau[s] = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
+                    }
+                    Ssum[s] = 1.0f;
                 }
-                for (int it = 0; it < a.cfg.n_iter; ++it) {
-                    float tm[SPW];
-                    bool moving = false;
+                PHASE(2);
+                if constexpr (MODE == SOLVE_SOFTMAX) {
                     wave_lds_fence();
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
-                        dm[s] *= 0.5f;
-                        tm[s] = tau[s] + dm[s];
-                        moving |= !(tm[s] == tau[s]);                       // NaN rows never settle: all n_iter steps
-                        red_write(red, s & 1, lane, eval(s, tm[s]), 0.f);
+                        float S = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            const float p = __builtin_amdgcn_exp2f((XG(s, j) - tau[s]) * L2E);
+                            S += p;
+                            XG(s, j) = p * VV(j >> 1)[j & 1];
+                        }
+                        red_write(red, s & 1, lane, S, 0.f);
                     }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const Red2 q = red_read(red, s & 1, c);
+                        Ssum[s] = (q.g0[0] + q.g1[0]) + (q.g2[0] + q.g3[0]);
+                    }
+                } else if constexpr (MODE == SOLVE_BISECT) {
+                    // The reference's bisection, statement for statement (utils/entmax.py:49-64), for alpha > 2, n_iter < 24
+                    // and ARMNET_F_FAITHFUL_BISECT: f_lo at tau_lo, then n_iter halvings; p is the one of the LAST tau_m.
+                    // t^(1/(alpha-1)) through the hardware log2/exp2 pair (2 transcendentals per element and step).
+                    f32x2 pkeep[SPW * NP];
+                    float f_lo[SPW], dm[SPW];
+                    auto eval = [&](int s_, float t_at) -> float {          // p(t_at) into pkeep, partial row sum
+                        const f32x2 tk = {t_at, t_at};
+                        f32x2 S2;
+#pragma unroll
+                        for (int jp = 0; jp < NP; ++jp) {
+                            const f32x2 t = pk_sub_clamp01(XP_GET(s_, jp), tk);     // tau >= max - 1  =>  x - tau <= 1
+                            f32x2 pv;
+                            pv[0] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[0]));   // log2(0) = -inf -> 0
+                            pv[1] = __builtin_amdgcn_exp2f(rr * __builtin_amdgcn_logf(t[1]));
+                            pkeep[s_ * NP + jp] = pv;
+                            S2 = jp == 0 ? pv : S2 + pv;
+                        }
+                        return S2[0] + S2[1];
+                    };
+                    wave_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) red_write(red, s & 1, lane, eval(s, tau[s]), 0.f);
                     wave_lds_fence();
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         const Red2 r = red_read(red, s & 1, c);
                         Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
-                        const float f_m = Ssum[s] - 1.0f;
-                        tau[s] = (f_m * f_lo[s] >= 0.f) ? tm[s] : tau[s];
+                        f_lo[s] = Ssum[s] - 1.0f;
+                        dm[s] = tau_hi[s] - tau[s];
                     }
-                    // once tau_lo + dm rounds to tau_lo in every row of the wave (dm below half an ulp: ~25 steps),
-                    // every later step would evaluate the same tau_m again: stopping here is bit-identical
-                    if (!__builtin_amdgcn_ballot_w64(moving)) break;
-                }
-                PHASE(3);
+                    for (int it = 0; it < a.cfg.n_iter; ++it) {
+                        float tm[SPW];
+                        bool moving = false;
+                        wave_lds_fence();
 #pragma unroll
-                for (int s = 0; s < SPW; ++s)
+                        for (int s = 0; s < SPW; ++s) {
+                            dm[s] *= 0.5f;
+                            tm[s] = tau[s] + dm[s];
+                            moving |= !(tm[s] == tau[s]);                       // NaN rows never settle: all n_iter steps
+                            red_write(red, s & 1, lane, eval(s, tm[s]), 0.f);
+                        }
+                        wave_lds_fence();
 #pragma unroll
-                    for (int jp = 0; jp < NP; ++jp) XP_SET(s, jp, pkeep[s * NP + jp] * VV(jp));
-            } else {
-                // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
-                // they converge.  When the loop ends every row's S was evaluated at its final threshold.
-                // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
-                // at the final threshold), which saves the two transcendentals per element of a final pass
-                f32x2 pkeep[MODE == SOLVE_NEWTON ? SPW * NP : 1];
-                for (int it = 0; it < kNewtonMaxIter; ++it) {
-                    wave_lds_fence();
+                        for (int s = 0; s < SPW; ++s) {
+                            const Red2 r = red_read(red, s & 1, c);
+                            Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
+                            const float f_m = Ssum[s] - 1.0f;
+                            tau[s] = (f_m * f_lo[s] >= 0.f) ? tm[s] : tau[s];
+                        }
+                        // once tau_lo + dm rounds to tau_lo in every row of the wave (dm below half an ulp: ~25 steps),
+                        // every later step would evaluate the same tau_m again: stopping here is bit-identical
+                        if (!__builtin_amdgcn_ballot_w64(moving)) break;
+                    }
+                    PHASE(3);
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                        for (int jp = 0; jp < NP; ++jp) XP_SET(s, jp, pkeep[s * NP + jp] * VV(jp));
+                } else {
+                    // Newton from the left on f(tau) = sum p(tau) - 1; wave-uniform loop, rows go passive as
+                    // they converge.  When the loop ends every row's S was evaluated at its final threshold.
+                    // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
+                    // at the final threshold), which saves the two transcendentals per element of a final pass
+                    f32x2 pkeep[MODE == SOLVE_NEWTON ? SPW * NP : 1];
+                    for (int it = 0; it < kNewtonMaxIter; ++it) {
+                        wave_lds_fence();
+#pragma unroll
+                        for (int s = 0; s < SPW; ++s) {
+                            const f32x2 tk = {tau[s], tau[s]};
+                            f32x2 S2, D2;
+#pragma unroll
+                            for (int jp = 0; jp < NP; ++jp) {
+                                const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                                f32x2 sv, dv;
+                                if constexpr (MODE == SOLVE_MICHELOT) {
+                                    sv = t;
+                                    dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
+                                } else if constexpr (MODE == SOLVE_NEWTON15) {
+                                    sv = t * t;
+                                    dv = t;
+                                } else {
+                                    f32x2 u;   // t^(r-1); log2(0) = -inf -> exp2(-inf) = 0 (r > 1)
+                                    u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
+                                    u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
+                                    sv = u * t;
+                                    dv = u;
+                                    pkeep[s * NP + jp] = sv;
+                                }
+                                S2 = jp == 0 ? sv : S2 + sv;
+                                D2 = jp == 0 ? dv : D2 + dv;
+                            }
+                            red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
+                        }
+                        wave_lds_fence();
+                        bool any_active = false;
+#pragma unroll
+                        for (int s = 0; s < SPW; ++s) {
+                            const Red2 r = red_read(red, s & 1, c);
+                            const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);     // {S, Dv} in one register pair
+                            float Dv = sd[1];
+                            if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
+                            if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
+                            Ssum[s] = sd[0];
+                            const float f = sd[0] - 1.0f;
+                            const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
+                            const bool act = (f > kNewtonTol) && (tn > tau[s]) && !dbg_no_solve;
+                            tau[s] = act ? tn : tau[s];
+                            any_active |= act;
+                        }
+                        if (!__builtin_amdgcn_ballot_w64(any_active)) break;
+                    }
+                    PHASE(3);
+                    // unnormalised weights p * values (armnet_1h.py:34)
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         const f32x2 tk = {tau[s], tau[s]};
-                        f32x2 S2, D2;
 #pragma unroll
                         for (int jp = 0; jp < NP; ++jp) {
-                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
-                            f32x2 sv, dv;
-                            if constexpr (MODE == SOLVE_MICHELOT) {
-                                sv = t;
-                                dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
-                            } else if constexpr (MODE == SOLVE_NEWTON15) {
-                                sv = t * t;
-                                dv = t;
+                            f32x2 p;
+                            if constexpr (MODE == SOLVE_NEWTON) {
+                                p = pkeep[s * NP + jp];
                             } else {
-                                f32x2 u;   // t^(r-1); log2(0) = -inf -> exp2(-inf) = 0 (r > 1)
-                                u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
-                                u[1] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[1]));
-                                sv = u * t;
-                                dv = u;
-                                pkeep[s * NP + jp] = sv;
+                                const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                                if constexpr (MODE == SOLVE_MICHELOT) p = t;
+                                else p = t * t;
                             }
-                            S2 = jp == 0 ? sv : S2 + sv;
-                            D2 = jp == 0 ? dv : D2 + dv;
+                            XP_SET(s, jp, p * VV(jp));
                         }
-                        red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
                     }
-                    wave_lds_fence();
-                    bool any_active = false;
-#pragma unroll
-                    for (int s = 0; s < SPW; ++s) {
-                        const Red2 r = red_read(red, s & 1, c);
-                        const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);     // {S, Dv} in one register pair
-                        float Dv = sd[1];
-                        if constexpr (MODE == SOLVE_NEWTON15) Dv *= 2.0f;
-                        if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
-                        Ssum[s] = sd[0];
-                        const float f = sd[0] - 1.0f;
-                        const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
-                        const bool act = (f > kNewtonTol) && (tn > tau[s]) && !dbg_no_solve;
-                        tau[s] = act ? tn : tau[s];
-                        any_active |= act;
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(any_active)) break;
                 }
-                PHASE(3);
-                // unnormalised weights p * values (armnet_1h.py:34)
+                // normaliser (entmax.py:63-64) folded into the exponent scale: 1/S by rcp + one Newton step
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
-                    const f32x2 tk = {tau[s], tau[s]};
-#pragma unroll
-                    for (int jp = 0; jp < NP; ++jp) {
-                        f32x2 p;
-                        if constexpr (MODE == SOLVE_NEWTON) {
-                            p = pkeep[s * NP + jp];
-                        } else {
-                            const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
-                            if constexpr (MODE == SOLVE_MICHELOT) p = t;
-                            else p = t * t;
-                        }
-                        XP_SET(s, jp, p * VV(jp));
-                    }
+                    const float S = Ssum[s] + (tau[s] - tau[s]);        // NaN threshold -> NaN row
+                    float r = __builtin_amdgcn_rcpf(S);
+                    r = fmaf(fmaf(-S, r, 1.0f), r, r);
+                    kexp[s] = MODEL == MODEL_GC_ARM ? r : L2E * r;      // GC-ARM: no outer exp (gc_arm.py:92-94)
                 }
-            }
-            // normaliser (entmax.py:63-64) folded into the exponent scale: 1/S by rcp + one Newton step
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                const float S = Ssum[s] + (tau[s] - tau[s]);        // NaN threshold -> NaN row
-                float r = __builtin_amdgcn_rcpf(S);
-                r = fmaf(fmaf(-S, r, 1.0f), r, r);
-                kexp[s] = L2E * r;
             }
 
             // ---- MFMA #2: Z^T[e, o] = sum_f X[f, e] * W[o, f]; sample chains interleaved -------------
             const f32x2 bn = *reinterpret_cast<const f32x2*>(p_bn + (nt * 16 + c) * 2);
+            const float xb = MODEL == MODEL_AFN ? p_x[nt * 16 + c] : 0.f;
             f32x4 c2[SPW][EB];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j)
+            for (int j = 0; j < NQ; ++j) {
+                f32x2 es = {0.f, 0.f};
+                if constexpr (MODEL == MODEL_GC_ARM) es = *reinterpret_cast<const f32x2*>(p_x + (4 * j + g) * 2);
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         const int q = s * NQ + j;
                         const int row = 16 * (q >> 2) + 4 * g + (q & 3);
-                        const float a2 = xt[row * ES + 16 * eb + c];
+                        float a2 = xt[row * ES + 16 * eb + c];
+                        // gc_arm.py:89: the interaction runs on emb_bn(exp(x)), field 4j+g of this lane group
+                        if constexpr (MODEL == MODEL_GC_ARM) a2 = fmaf(__builtin_amdgcn_exp2f(a2 * L2E), es[0], es[1]);
                         if (dbg_no_mfma) {
                             const float w = a2 * XG(s, j);
                             c2[s][eb] = j == 0 ? f32x4{w, w, w, w} : c2[s][eb] + w;
@@ -637,6 +694,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                         else
                             c2[s][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, XG(s, j), c2[s][eb], 0, 0, 0);
                     }
+            }
             PHASE(4);
             // ---- epilogue: exp(z / S) = exp2(z * log2e / S) (rel. error <= ~|z| * 1.3e-7), BN affine, store
             const bool fast_store = full_rows && 16 * nt + 16 <= O;      // wave-uniform: whole 16-byte stores
@@ -653,10 +711,17 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                         const f32x2 ke = {kexp[s], kexp[s]};
 #pragma unroll
                         for (int eb = 0; eb < EB; ++eb) {
-                            const f32x2 zlo = f32x2{c2[s][eb][0], c2[s][eb][1]} * ke;
-                            const f32x2 zhi = f32x2{c2[s][eb][2], c2[s][eb][3]} * ke;
-                            const f32x2 elo = {__builtin_amdgcn_exp2f(zlo[0]), __builtin_amdgcn_exp2f(zlo[1])};
-                            const f32x2 ehi = {__builtin_amdgcn_exp2f(zhi[0]), __builtin_amdgcn_exp2f(zhi[1])};
+                            f32x2 zlo = f32x2{c2[s][eb][0], c2[s][eb][1]} * ke;
+                            f32x2 zhi = f32x2{c2[s][eb][2], c2[s][eb][3]} * ke;
+                            if constexpr (MODEL == MODEL_AFN) {                 // + (bias + sum_f W t_f) * log2(e)
+                                zlo += f32x2{xb, xb};
+                                zhi += f32x2{xb, xb};
+                            }
+                            f32x2 elo = zlo, ehi = zhi;
+                            if constexpr (MODEL != MODEL_GC_ARM) {
+                                elo = f32x2{__builtin_amdgcn_exp2f(zlo[0]), __builtin_amdgcn_exp2f(zlo[1])};
+                                ehi = f32x2{__builtin_amdgcn_exp2f(zhi[0]), __builtin_amdgcn_exp2f(zhi[1])};
+                            }
                             const f32x2 vlo = __builtin_elementwise_fma(elo, bn0, bn1);
                             const f32x2 vhi = __builtin_elementwise_fma(ehi, bn0, bn1);
                             const int e = 16 * eb + 4 * g;
@@ -701,7 +766,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 
 // SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
 // nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
-template <int E, int NQ, int MODE, int SRC>
+template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
     constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
     // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
@@ -714,7 +779,8 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
     const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +
-                        (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32) * sizeof(float);
+                        (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32 +
+                        (MODEL == MODEL_GC_ARM ? (size_t)NQ * 8 : MODEL == MODEL_AFN ? (size_t)NT * 16 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
     const int64_t ngroups = (a.B + SPW - 1) / SPW;
     const int64_t blocks = (ngroups + 3) / 4;
@@ -731,7 +797,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
         if (want < 1) want = 1;
     }
 #endif
-    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS>;
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -740,15 +806,27 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     return ARMNET_OK;
 }
 
-template <int E, int NQ, int SRC>
+template <int E, int NQ, int SRC, int MODEL = MODEL_ARM>
 static int launch_mode(const FusedArgs& a, hipStream_t st) {
     switch (a.cfg.mode) {
-        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC>(a, st);
-        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);
-        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);
-        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);
-        case SOLVE_BISECT: return launch_one<E, NQ, SOLVE_BISECT, SRC>(a, st);
+        case SOLVE_SOFTMAX: return launch_one<E, NQ, SOLVE_SOFTMAX, SRC, MODEL>(a, st);
+        case SOLVE_MICHELOT: return launch_one<E, NQ, SOLVE_MICHELOT, SRC, MODEL>(a, st);
+        case SOLVE_NEWTON15: return launch_one<E, NQ, SOLVE_NEWTON15, SRC, MODEL>(a, st);
+        case SOLVE_NEWTON: return launch_one<E, NQ, SOLVE_NEWTON, SRC, MODEL>(a, st);
+        case SOLVE_BISECT: return launch_one<E, NQ, SOLVE_BISECT, SRC, MODEL>(a, st);
         default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+// sibling models (ids only): GC-ARM with every sparse map, AFN has none (one instantiation per shape)
+template <int E, int NQ, int MODEL>
+static int launch_sibling(const FusedArgs& a, hipStream_t st) {
+    if (a.rows != nullptr) return ARMNET_ERR_UNSUPPORTED;
+    if constexpr (MODEL == MODEL_AFN) {
+        return a.id_type == ARMNET_ID_I64 ? launch_one<E, NQ, SOLVE_SOFTMAX, 0, MODEL>(a, st)
+                                          : launch_one<E, NQ, SOLVE_SOFTMAX, 1, MODEL>(a, st);
+    } else {
+        return a.id_type == ARMNET_ID_I64 ? launch_mode<E, NQ, 0, MODEL>(a, st) : launch_mode<E, NQ, 1, MODEL>(a, st);
     }
 }
 
@@ -766,5 +844,9 @@ static int launch_src(const FusedArgs& a, hipStream_t st) {
 int launch_mfma_e16(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e32(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e64(const FusedArgs& a, int nq, hipStream_t st);
+int launch_gc_e16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_gc_e32(const FusedArgs& a, int nq, hipStream_t st);
+int launch_gc_e64(const FusedArgs& a, int nq, hipStream_t st);
+int launch_afn(const FusedArgs& a, int ep, int nq, hipStream_t st);
 
 }  // namespace armnet

@@ -119,3 +119,63 @@ def test_out_of_range_id_raises_indexerror_for_the_siblings():
         bad[2, 5] = meta["ctor"]["nfeat"]
         with pytest.raises(IndexError), torch.no_grad():
             m({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
+
+
+def _grid_model(variant, F, E, K, nhid, alpha, seed):
+    ctor = dict(nfield=F, nfeat=997, nemb=E, nhead=K, alpha=alpha, nhid=nhid, mlp_nlayer=1, mlp_nhid=16, dropout=0.0,
+                ensemble=False, deep_nlayer=1, deep_nhid=8)
+    torch.manual_seed(seed)
+    m = _build({"variant": variant, "ctor": ctor})
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                                  # trained-like statistics: non-trivial BN affines, wide gates
+        for name, p in m.named_parameters():
+            if "bn" in name:
+                p.copy_(torch.rand(p.shape, generator=g) * 0.8 + 0.6 if name.endswith("weight")
+                        else torch.randn(p.shape, generator=g) * 0.2)
+        for name, b in m.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.3)
+            if name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) * 1.5 + 0.5)
+        if variant == "gc":
+            m.embedding.embedding.weight.mul_(6.0)
+            m.attn_layers.Q.mul_(3.0)
+    return ctor, m
+
+
+# (variant, nfield, nemb, nhead, nhid, alpha): every padded width, one- and two-sample wave groups, neuron slices,
+# odd widths, every sparse map of the GC-ARM mode
+GRID = [("gc", 39, 16, 2, 16, 2.0), ("gc", 39, 16, 1, 24, 1.5), ("gc", 22, 10, 4, 8, 1.7), ("gc", 10, 5, 1, 7, 1.0),
+        ("gc", 13, 32, 2, 20, 2.5), ("gc", 43, 64, 1, 33, 1.3), ("gc", 3, 4, 1, 1, 2.0), ("gc", 30, 24, 3, 100, 1.5),
+        ("afn", 39, 16, 1, 32, 0.0), ("afn", 22, 10, 1, 600, 0.0), ("afn", 7, 5, 1, 9, 0.0), ("afn", 13, 32, 1, 40, 0.0),
+        ("afn", 43, 64, 1, 17, 0.0), ("afn", 48, 7, 1, 3, 0.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,F,E,K,nhid,alpha", GRID)
+def test_matrix_core_and_generic_block_match_the_oracle(variant, F, E, K, nhid, alpha):
+    """The siblings run as modes of the matrix-core kernel wherever the ARM block does; the shape-agnostic kernel stays
+    the fallback.  Both are held to the oracle on the same batch (ragged size: short last wave group)."""
+    from armnet_hip import native
+    ctor, m = _grid_model(variant, F, E, K, nhid, alpha, seed=F * 100 + E)
+    O = K * nhid if variant == "gc" else nhid
+    assert native.fused_kernel_kind(F, E, O, max(alpha, 1.0)) == 1
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    B = 515
+    ids = torch.randint(0, ctor["nfeat"], (B, F), generator=g)
+    vals = torch.rand(B, F, generator=g) * 1.2 - 0.1
+    want = _oracle({"variant": variant, "ctor": ctor}, sd, ids.numpy(), vals.numpy())
+    m = m.to(DEV)
+    if variant == "afn":
+        m.embedding_clip()                                 # forward() does this before the block (afn.py:56)
+    outs = []
+    for flags in (0, native.F_FORCE_GENERIC):
+        m.kernel_flags = flags
+        v = vals.clone().to(DEV)
+        with torch.no_grad():
+            block = (m.arm_block if variant == "gc" else m.afn_block)(ids.to(DEV), v)
+        np.testing.assert_array_equal(v.cpu().numpy(), want["vals_clamped"])
+        assert_close(block.cpu().numpy(), want["x_arm"], TOL, f"{variant} flags={flags}")
+        outs.append(block)
+    assert torch.isfinite(outs[0]).all()
