@@ -31,6 +31,7 @@ for name, m, blk in (("gc_arm a=2.0 K=1 O=64", GC_ARMModel(F, nfeat, E, 1, 2.0, 
                      ("gc_arm a=1.7 K=8 O=64", GC_ARMModel(F, nfeat, E, 8, 1.7, 8, 3, 512, 0.0, False, 1, 8), "arm_block"),
                      ("afn O=64", AFNModel(F, nfeat, E, 64, 3, 512, 0.0, False, 1, 8), "afn_block")):
     m = m.eval().to(dev)
+    m.check_ids = False                                   # no host sync per call
     res = {}
     with torch.no_grad():
         for label, flags in (("matrix-core", 0), ("generic", native.F_FORCE_GENERIC)):

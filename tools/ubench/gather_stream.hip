@@ -50,23 +50,30 @@ __global__ void __launch_bounds__(256) k(const long long* ids, const float* vals
     if (acc[0] == 12345.f) out[0] = acc[1];
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // ROT distinct batches (ids, vals, out), visited in turn like bench.py --rotate: 4 x 165 MB does not stay in the
+    // 256 MB Infinity Cache, only the 64 MB table can.  `gather_stream 1` replays one batch (the round-1 number).
+    const int ROT = argc > 1 ? atoi(argv[1]) : 4;
     const int B = 65536, F = 39, NF = 1000000;
+    std::vector<long long*> ids(ROT); std::vector<float*> vals(ROT), out(ROT);
+    float* table;
+    hipMalloc(&table, (size_t)NF * 64); hipMemset(table, 0, (size_t)NF * 64);
     std::vector<long long> h_ids((size_t)B * F);
     srand(1);
-    for (auto& x : h_ids) x = ((long long)rand() * 32768 + rand()) % NF;
-    long long* ids; float *vals, *table, *out;
-    hipMalloc(&ids, h_ids.size() * 8); hipMalloc(&vals, h_ids.size() * 4);
-    hipMalloc(&table, (size_t)NF * 64); hipMalloc(&out, (size_t)B * 2048);
-    hipMemcpy(ids, h_ids.data(), h_ids.size() * 8, hipMemcpyHostToDevice);
-    hipMemset(vals, 0, h_ids.size() * 4); hipMemset(table, 0, (size_t)NF * 64);
+    for (int r = 0; r < ROT; ++r) {
+        for (auto& x : h_ids) x = ((long long)rand() * 32768 + rand()) % NF;
+        hipMalloc(&ids[r], h_ids.size() * 8); hipMalloc(&vals[r], h_ids.size() * 4); hipMalloc(&out[r], (size_t)B * 2048);
+        hipMemcpy(ids[r], h_ids.data(), h_ids.size() * 8, hipMemcpyHostToDevice);
+        hipMemset(vals[r], 0, h_ids.size() * 4);
+    }
     const double bytes_rd = (double)B * F * (8 + 4 + 64), bytes_wr = (double)B * 2048;
+    printf("rotating over %d batches\n", ROT);
     auto run = [&](auto kern, int blocks, int st, const char* name) {
-        for (int i = 0; i < 3; ++i) kern<<<blocks, 256>>>(ids, vals, table, out, B, F, st);
+        for (int i = 0; i < 4; ++i) kern<<<blocks, 256>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) kern<<<blocks, 256>>>(ids, vals, table, out, B, F, st);
+        for (int i = 0; i < 20; ++i) kern<<<blocks, 256>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
         printf("%-34s blocks=%5d store=%d : %7.1f us  %6.0f GB/s\n", name, blocks, st, ms * 1e3,
