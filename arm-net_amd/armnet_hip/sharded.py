@@ -12,7 +12,9 @@ anywhere in the step):
     consume    armnet_fused_fwd_f32 with table = received rows, ids = perm_pad (int32)  (no un-permute pass)
 
 The split sizes are known to the host without looking at the data, so routing, both exchanges, the gather and the
-fused kernel are enqueued back to back (and micro-batches really overlap).  The price is the slack of the slots
+fused kernel are enqueued back to back (and micro-batches really overlap).  Nothing in a step is shared with another
+step except the overflow flag (an atomic OR), so a serving loop may keep several steps in flight on different streams
+(bench.py --in-flight 2): the row exchange of step i+1 then runs under the fused kernel of step i.  The price is the slack of the slots
 (25 % more exchanged bytes; none with de-duplication, whose slot is the owner's whole shard at most).  A slot that
 overflows sets a device flag; `overflowed()` reduces it over the ranks — the one place that synchronises, called by
 `sharded_arm_block` only when the caller asked for checked execution — and the step is then repeated with the
@@ -35,7 +37,8 @@ class HipShardOps:
     """Device kernels of the sharded lookup (C ABI).  CPU tensors are rejected by the binding."""
 
     def __init__(self):
-        self._ws = None          # workspace of the de-duplicating route, reused across steps
+        self._ws = {}            # workspace of the de-duplicating route, reused across steps: one per (device, stream),
+                                 # so that steps in flight on different streams never share it
 
     def route(self, ids_flat, R, nfeat, dedup=False, id_status=None):
         """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once.
@@ -47,9 +50,11 @@ class HipShardOps:
         perm = torch.empty(n, device=dev, dtype=torch.int32)
         if dedup:
             need = native.shard_route_unique_ws_bytes(R, nfeat)
-            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
-            native.shard_route_unique_ids(n, ids_flat, R, nfeat, counts, send_local, perm, self._ws, id_status)
+            key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = self._ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+            native.shard_route_unique_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws, id_status)
         else:
             ws = torch.empty(max(native.shard_route_ws_bytes(n, R), 4), device=dev, dtype=torch.uint8)
             native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws, id_status)

@@ -69,6 +69,8 @@ def parse():
                     help="row-sharded variant: fixed-capacity equal-split exchanges (no host sync) or exact splits")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="row-sharded variant: slices per step whose exchanges overlap the previous slice's kernel")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -280,7 +282,7 @@ def main():
     # Row-sharded variant: same model, same batches, the table row-sharded over the ranks and fetched by all-to-all.
     # It runs AFTER the headline numbers are final and under a watchdog: whatever happens in there (an exception on
     # one rank, a collective that never completes) must not cost the main line.
-    sharded = {"ms": float("nan"), "err": None, "done": False}
+    sharded = {"ms": float("nan"), "err": None, "done": False, "by_in_flight": {}, "in_flight": 1}
     if a.shard == "both":
         import threading
 
@@ -293,22 +295,42 @@ def main():
                 model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
                 turn = [0]
 
-                def step_sharded():
-                    k = turn[0] % NB
-                    turn[0] += 1
-                    with torch.no_grad():
-                        return model.arm_block(batches[k][0], batches[k][1])
+                # `in_flight` steps on alternating streams (a serving loop with that many batches in flight): the row
+                # exchange of step i+1 overlaps the fused kernel of step i.  The collectives stay in issue order on the
+                # process group's own stream; the timed region ends with a device-wide synchronize.  Measured with one
+                # step in flight first, then with a.in_flight: the faster one is the row-sharded number, both are reported
+                # (and a failure of the second mode keeps the first).
+                for nfl in sorted({1, max(1, a.in_flight)}):
+                    try:
+                        streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+                        for s_ in streams:
+                            s_.wait_stream(torch.cuda.current_stream())
+                        turn = [0]
 
-                for _ in range(a.warmup):
-                    step_sharded()
-                ms, _ = timed(step_sharded, a.steps, sync_all)
-                ts = torch.tensor([ms], device=dev, dtype=torch.float64)
-                if use_dist:
-                    dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-                sharded["ms"] = float(ts.item())
-                # the fixed-capacity protocol never looked at a count on the host: check its overflow flag ONCE, after
-                # the timed steps (a set flag means some lookups read a wrong row: the number would be void)
-                sharded["overflow"] = bool(model._shard.overflowed())
+                        def step_sharded():
+                            k = turn[0] % NB
+                            s_ = streams[turn[0] % nfl]
+                            turn[0] += 1
+                            with torch.no_grad(), torch.cuda.stream(s_):
+                                return model.arm_block(batches[k][0], batches[k][1])
+
+                        for _ in range(a.warmup):
+                            step_sharded()
+                        ms, _ = timed(step_sharded, a.steps, sync_all)
+                        ts = torch.tensor([ms], device=dev, dtype=torch.float64)
+                        if use_dist:
+                            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                        # the fixed-capacity protocol never looked at a count on the host: check its overflow flag ONCE,
+                        # after the timed steps (a set flag means some lookups read a wrong row: the number would be void)
+                        if bool(model._shard.overflowed()):
+                            sharded["overflow"] = True
+                        sharded["by_in_flight"][str(nfl)] = float(ts.item())
+                    except Exception as e:  # noqa: BLE001
+                        if not sharded["by_in_flight"]:
+                            raise
+                        sharded["in_flight_err"] = f"in_flight={nfl}: {type(e).__name__}: {e}"
+                best = min(sharded["by_in_flight"], key=sharded["by_in_flight"].get)
+                sharded["ms"], sharded["in_flight"] = sharded["by_in_flight"][best], int(best)
             except Exception as e:  # noqa: BLE001
                 sharded["err"] = f"{type(e).__name__}: {e}"
             sharded["done"] = True
@@ -400,13 +422,18 @@ def main():
         elif a.shard == "both":
             line["row_sharded"] = {
                 "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
-                "ms_per_step": sharded_ms / a.steps,
+                "ms_per_step": sharded_ms / a.steps, "steps_in_flight": sharded["in_flight"],
+                "samples_per_s_by_steps_in_flight": {k: world * a.batch * a.steps / (v * 1e-3)
+                                                     for k, v in sharded["by_in_flight"].items()},
+                "in_flight_error": sharded.get("in_flight_err"),
                 "note": f"(= `value`) the block with the table row-sharded (row i on rank i mod {world}), no host "
                         f"synchronisation in the step: HIP routing with per-rank id de-duplication (direct-address mark + "
                         f"scan), fixed-capacity slots, equal-split all_to_all_single of int32 row indices, owner-side "
                         f"gather, equal-split all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
                         f"{a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB per rank per step, {(world - 1) / world:.0%} of it "
-                        f"across xGMI), fused kernel over (rows, perm); overflow flag checked after the timed steps"}
+                        f"across xGMI), fused kernel over (rows, perm); overflow flag checked after the timed steps; "
+                        f"steps_in_flight > 1: consecutive steps alternate between that many streams, so the row exchange "
+                        f"of one step runs under the fused kernel of the previous one"}
         if a.shard == "rows":
             line["row_sharded_overflow"] = sharded_overflow
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":

@@ -66,3 +66,55 @@ def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol
         assert p.exitcode == 0
     for rank, ok, err in res:
         assert ok, f"rank {rank}: sharded result differs from replicated by {err}"
+
+
+def _worker_in_flight(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from golden_util import load
+        from model_util import build_model
+        dev = "cuda:0"
+        meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
+        c = meta["ctor"]
+        g = torch.Generator().manual_seed(90 + rank)
+        B, K = 4096, 6                                         # 160k lookups of a 5k-row table: de-duplication on
+        batches = [(torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g).to(dev),
+                    torch.rand(B, c["nfield"], generator=g).to(dev)) for _ in range(K)]
+        m = build_model(meta, sd, dev)
+        m.check_ids = False                                    # no host sync inside a step
+        with torch.no_grad():
+            want = [m.arm_block(i, v.clone()) for i, v in batches]
+            m.shard_embedding()
+            m._shard.dedup, m._shard.protocol = True, "fixed"
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
+            got = []
+            for k, (i, v) in enumerate(batches):               # K steps enqueued back to back, two in flight
+                with torch.cuda.stream(streams[k % 2]):
+                    got.append(m.arm_block(i, v.clone()))
+            torch.cuda.synchronize()
+            assert not m._shard.overflowed()
+        q.put((rank, all(bool(torch.equal(a, b)) for a, b in zip(got, want)), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_steps_in_flight_on_two_streams_are_bit_equal_to_replicated():
+    """bench.py --in-flight 2: consecutive steps alternate between two streams; nothing but the overflow flag is shared
+    between steps (the de-duplication workspace is per stream)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, 2, 29677, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, _ in res:
+        assert ok, f"rank {rank}: a step in flight differs from the replicated result"
