@@ -30,7 +30,7 @@ EXPORTS = (
     "armnet_bn_apply_f32", "armnet_bn_bwd_reduce_f32", "armnet_bn_bwd_coef_f32", "armnet_bn_bwd_apply_f32",
     "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
-    "armnet_abs_clamp_min_f32", "armnet_shard_pad_route",
+    "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
 )
 
 _lib = None
@@ -422,3 +422,12 @@ def shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, ove
         check(load().armnet_shard_pad_route(ctypes.c_int64(n), int(R), ctypes.c_int64(cap), _ptr(counts),
                                             _ptr(send_local), _ptr(perm), _ptr(send_pad), _ptr(perm_pad),
                                             _ptr(overflow), _stream()))
+
+
+def shard_direct_perm(n, ids, R, nfeat, perm, id_status=None):
+    """perm[i] = (id % R) * ceil(nfeat / R) + id // R: address of id i's row in the all-gathered shards"""
+    _ids_ok(ids)
+    _i32_ok(perm=perm)
+    with _on(ids, perm, id_status):
+        check(load().armnet_shard_direct_perm(ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R),
+                                              ctypes.c_int64(nfeat), _ptr(perm), _ptr(id_status), _stream()))

@@ -23,6 +23,12 @@ overflows sets a device flag; `overflowed()` reduces it over the ranks — the o
     exchange   all_gather of the R counts  ->  every rank knows the R x R split matrix (tiny, then .cpu())
     exchange   all_to_all_single of int32 local row indices / of the rows, data-dependent splits
 
+When the batch covers the table — the slot of the de-duplicated request list would be the owner's whole shard
+(about 1.25 n >= nfeat: the headline shape, 2.56 M lookups of 1 M rows per rank) — request lists are pointless: the
+owners ship their shards as they are (ONE all_gather_into_tensor of ceil(nfeat / R) rows per rank, the same bytes the
+row exchange would move), no routing, no request exchange, no owner-side gather, and perm is the direct address
+(id % R) * L + id // R (armnet_shard_direct_perm).  The gathered buffer is transient; the table stays sharded at rest.
+
 The arithmetic of the fused block is untouched: the sharded result is bit-equal to the single-GPU one.
 `ops` abstracts the two device kernels so that the routing logic can be exercised by world_size-2
 gloo tests on CPU with a test double (tests/test_sharded_gloo.py); the product default is HipShardOps.
@@ -75,6 +81,12 @@ class HipShardOps:
         native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
         return send_pad, perm_pad
 
+    def direct_perm(self, ids_flat, R, nfeat, id_status=None):
+        """-> perm [n] int32: address of every id's row in the all-gathered shards (armnet_shard_direct_perm)"""
+        perm = torch.empty(ids_flat.numel(), device=ids_flat.device, dtype=torch.int32)
+        native.shard_direct_perm(ids_flat.numel(), ids_flat, R, nfeat, perm, id_status)
+        return perm
+
 
 def shard_rows(full_table, rank, world):
     """Local shard of a full [nfeat, E] table under the modulo partition."""
@@ -90,6 +102,10 @@ class RowShardedTable:
         self._overflow = None     # device flag of the fixed protocol, OR-ed by every lookup since the last check
         self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
         self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
+        self.whole_shard = "auto" # fixed protocol: all-gather the shards when the de-duplicated slot would be the whole
+                                  # shard anyway ("auto"), never (False)
+        self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces)
+        self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
         self.table_local = table_local
         self.nfeat = int(nfeat)
         self.group = group
@@ -147,6 +163,15 @@ class RowShardedTable:
         dedup = (8 * n >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
         if self._overflow is None or self._overflow.device != dev:
             self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+        # every rank must use the same slot size: it is a function of the batch shape only, so the ranks must hand in
+        # equally shaped batches per step (data-parallel inference with padded / dropped last batches), or fix the
+        # size for good with `slot_lookups`
+        cap = self.capacity(int(getattr(self, "slot_lookups", None) or max(n, 1)), dedup)
+        L = (self.nfeat + R - 1) // R
+        if dedup and cap >= L and self.whole_shard == "auto":
+            self.last_path = "whole_shards"
+            return self._lookup_whole_shards(flat, id_status)
+        self.last_path = "fixed"
         if n == 0:                                     # an empty slice still takes part in the exchanges
             counts = torch.zeros(R, device=dev, dtype=torch.int32)
             send_local = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -155,10 +180,6 @@ class RowShardedTable:
             counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
         else:
             counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
-        # every rank must use the same slot size: it is a function of the batch shape only, so the ranks must hand in
-        # equally shaped batches per step (data-parallel inference with padded / dropped last batches), or fix the
-        # size for good with `slot_lookups`
-        cap = self.capacity(int(getattr(self, "slot_lookups", None) or max(n, 1)), dedup)
         send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
         E = self.table_local.shape[1]
         if R == 1 and not dist.is_initialized():
@@ -170,7 +191,34 @@ class RowShardedTable:
         self._all_to_all(rows_in, rows_out, None, None)
         return rows_in, perm_pad
 
+    def _lookup_whole_shards(self, flat, id_status=None):
+        """The de-duplicated request list of this batch would cover (nearly) every row of every shard — its slot IS the
+        shard — so the owners ship their shards as they are: one all-gather, no routing, no request exchange, no
+        owner-side gather.  The received buffer is transient (the table stays sharded at rest); id i's row sits at the
+        direct address (id % R) * L + id // R.  Exact by construction (nothing can overflow)."""
+        R = self.world
+        L = (self.nfeat + R - 1) // R
+        E = self.table_local.shape[1]
+        if self._table_ag is None:                     # (a changed table re-creates this object: _refresh_shard)
+            t = self.table_local
+            if t.shape[0] < L:                         # the last shards are one row short: pad (a copy, made once)
+                t = torch.cat([t, t.new_zeros(L - t.shape[0], E)])
+            self._table_ag = t
+        perm = (self.ops.direct_perm(flat, R, self.nfeat, id_status) if flat.numel() else
+                torch.empty(0, device=flat.device, dtype=torch.int32))
+        if R == 1 and not dist.is_initialized():
+            return self._table_ag, perm
+        rows_in = torch.empty(R * L, E, device=flat.device, dtype=torch.float32)
+        if self._via_host:
+            h = torch.empty(R * L, E, dtype=torch.float32)
+            dist.all_gather_into_tensor(h, self._table_ag.cpu(), group=self.group)
+            rows_in.copy_(h)
+        else:
+            dist.all_gather_into_tensor(rows_in, self._table_ag, group=self.group)
+        return rows_in, perm
+
     def _lookup_exact(self, ids, id_status=None):
+        self.last_path = "exact"
         R = self.world
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()

@@ -63,9 +63,48 @@ int launch_shard_pad(int64_t n, int R, int64_t cap, const int32_t* counts, const
     return ARMNET_OK;
 }
 
+// Whole-shard exchange (the batch asks for most of every shard: the slot of the de-duplicated request list would be
+// the shard itself): the owners ship their shards as they are (all-gather, L = ceil(nfeat / R) rows each, the last
+// shards padded by one row), no request list, no owner-side gather; row `id` then sits at the direct address
+// (id % R) * L + id / R of the gathered buffer.  Out-of-range ids are flagged and read row 0.
+template <typename IdT>
+__global__ void __launch_bounds__(256)
+shard_direct_perm_kernel(int64_t n, const IdT* __restrict__ ids, int R, int64_t nfeat, int64_t L,
+                         int32_t* __restrict__ perm, int32_t* id_status) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = (uint64_t)(int64_t)ids[i];
+        const bool bad = v >= (uint64_t)nfeat;
+        if (bad && id_status) atomicOr(id_status, 1);
+        const uint32_t id = bad ? 0u : (uint32_t)v;
+        perm[i] = (int32_t)((int64_t)(id % (uint32_t)R) * L + id / (uint32_t)R);
+    }
+}
+
+int launch_shard_direct_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm,
+                             int32_t* id_status, hipStream_t st) {
+    const int64_t L = (nfeat + R - 1) / R;
+    if ((int64_t)R * L >= ((int64_t)1 << 31) || nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    if (n == 0) return ARMNET_OK;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (id_type == ARMNET_ID_I64)
+        shard_direct_perm_kernel<int64_t><<<(int)grid, 256, 0, st>>>(n, (const int64_t*)ids, R, nfeat, L, perm, id_status);
+    else
+        shard_direct_perm_kernel<int32_t><<<(int)grid, 256, 0, st>>>(n, (const int32_t*)ids, R, nfeat, L, perm, id_status);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
 }  // namespace armnet
 
 using namespace armnet;
+
+extern "C" int armnet_shard_direct_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm,
+                                        int32_t* id_status, void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || (n > 0 && (!ids || !perm))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_direct_perm(n, ids, id_type, R, nfeat, perm, id_status, (hipStream_t)stream);
+}
 
 extern "C" int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts, const int32_t* send_local,
                                       const int32_t* perm, int32_t* send_pad, int32_t* perm_pad, int32_t* overflow,

@@ -69,6 +69,9 @@ def parse():
                     help="row-sharded variant: fixed-capacity equal-split exchanges (no host sync) or exact splits")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="row-sharded variant: slices per step whose exchanges overlap the previous slice's kernel")
+    ap.add_argument("--whole-shard", choices=["auto", "off"], default="auto",
+                    help="row-sharded variant: all-gather the shards when the batch covers the table (auto) or always "
+                         "answer request lists (off)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -293,6 +296,7 @@ def main():
                 model._shard.micro_batches = a.micro_batches
                 model._shard.protocol = a.protocol
                 model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
+                model._shard.whole_shard = "auto" if a.whole_shard == "auto" else False
                 turn = [0]
 
                 # `in_flight` steps on alternating streams (a serving loop with that many batches in flight): the row
@@ -329,6 +333,7 @@ def main():
                         if not sharded["by_in_flight"]:
                             raise
                         sharded["in_flight_err"] = f"in_flight={nfl}: {type(e).__name__}: {e}"
+                sharded["exchange"] = getattr(model._shard, "last_path", None)
                 best = min(sharded["by_in_flight"], key=sharded["by_in_flight"].get)
                 sharded["ms"], sharded["in_flight"] = sharded["by_in_flight"][best], int(best)
             except Exception as e:  # noqa: BLE001
@@ -425,9 +430,13 @@ def main():
                 "ms_per_step": sharded_ms / a.steps, "steps_in_flight": sharded["in_flight"],
                 "samples_per_s_by_steps_in_flight": {k: world * a.batch * a.steps / (v * 1e-3)
                                                      for k, v in sharded["by_in_flight"].items()},
-                "in_flight_error": sharded.get("in_flight_err"),
+                "in_flight_error": sharded.get("in_flight_err"), "exchange": sharded.get("exchange"),
                 "note": f"(= `value`) the block with the table row-sharded (row i on rank i mod {world}), no host "
-                        f"synchronisation in the step: HIP routing with per-rank id de-duplication (direct-address mark + "
+                        f"synchronisation in the step.  exchange = whole_shards: this batch asks for (nearly) every row "
+                        f"of every shard ({a.batch * a.nfield} lookups of {a.nfeat} rows per rank), so the owners ship "
+                        f"their shards as they are — one all_gather_into_tensor of {a.nfeat * a.nemb * 4 / 1e6:.0f} MB "
+                        f"per rank and step into a transient buffer, direct row addresses — instead of answering "
+                        f"request lists.  exchange = fixed (sparser batches, --whole-shard off): HIP routing with per-rank id de-duplication (direct-address mark + "
                         f"scan), fixed-capacity slots, equal-split all_to_all_single of int32 row indices, owner-side "
                         f"gather, equal-split all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
                         f"{a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB per rank per step, {(world - 1) / world:.0%} of it "

@@ -241,6 +241,15 @@ int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts,
                            const int32_t* perm, int32_t* send_pad, int32_t* perm_pad, int32_t* overflow, void* stream);
 
 /*
+ * Whole-shard exchange of the row-sharded lookup (csrc/shard_pad.hip): when a batch asks for most of every shard the
+ * owners all-gather their shards (L = ceil(nfeat / R) rows each) instead of answering request lists; perm[i] is then
+ * the direct address (id % R) * L + id / R of id i's row in the gathered [R * L, E] buffer.  ids int64 / int32;
+ * *id_status |= 1 for an id outside [0, nfeat) (such an id reads row 0).
+ */
+int armnet_shard_direct_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm,
+                             int32_t* id_status, void* stream);
+
+/*
  * Sibling models on the same kernels, eval mode.
  *
  * armnet_gc_fused_fwd_f32 — models/gc_arm.py:82-95 (GC_ARMModel.forward up to arm_bn):

@@ -38,6 +38,12 @@ class NumpyShardOps:
     def gather(self, local_idx, table_local):
         return table_local[local_idx.long()].contiguous()
 
+    def direct_perm(self, ids_flat, R, nfeat, id_status=None):
+        """contract of armnet_shard_direct_perm: address of the row in the all-gathered (padded) shards"""
+        ids = ids_flat.numpy().astype(np.int64)
+        L = (nfeat + R - 1) // R
+        return torch.from_numpy(((ids % R) * L + ids // R).astype(np.int32))
+
     def pad_route(self, counts, send_local, perm, R, cap, overflow):
         """contract of armnet_shard_pad_route: R equal slots of cap indices, index 0 in the unused entries"""
         c = counts.numpy().astype(np.int64)
@@ -119,6 +125,17 @@ def test_fixed_capacity_protocol_without_host_sync_gloo(world, dedup):
     res = _run(world, port, (1001, 8, 37, 5, dedup, "fixed", 1.25))
     assert [r[1] for r in res] == [True] * world, res
     assert len({r[2] for r in res}) == 1 and res[0][2] % world == 0      # equal slots on every rank
+    assert not any(r[3] for r in res)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_whole_shard_exchange_when_the_batch_covers_the_table_gloo(world):
+    """1 500 lookups of a 1 001-row table: the de-duplicated slot would be the whole shard, so the owners all-gather
+    their shards (padded to ceil(nfeat / R) rows: 501 + 500, 334 + 334 + 333) and perm is the direct address"""
+    port = 35500 + os.getpid() % 2000 + world
+    res = _run(world, port, (1001, 8, 300, 5, True, "fixed", 1.25))
+    assert [r[1] for r in res] == [True] * world, res
+    assert all(r[2] == world * ((1001 + world - 1) // world) for r in res), res     # R * L rows received
     assert not any(r[3] for r in res)
 
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dedup, micro, q, protocol="exact"):
+def _worker(rank, world, port, dedup, micro, q, protocol="exact", whole="auto"):
     for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,6 +40,7 @@ def _worker(rank, world, port, dedup, micro, q, protocol="exact"):
             m._shard.dedup = dedup
             m._shard.protocol = protocol
             m._shard.micro_batches = micro
+            m._shard.whole_shard = whole
             assert m._shard.world == world and m._shard._via_host
             got = m.arm_block(ids.to(dev), vals.clone().to(dev))
             assert not (protocol == "fixed" and m._shard.overflowed())
@@ -48,16 +49,20 @@ def _worker(rank, world, port, dedup, micro, q, protocol="exact"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dedup,micro,protocol", [(False, 1, "exact"), (True, 1, "exact"), (True, 3, "exact"),
-                                                  (False, 500, "exact"), (False, 1, "fixed"), (True, 1, "fixed"),
-                                                  (False, 3, "fixed"), (True, 50, "fixed")])
-def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol):
+@pytest.mark.parametrize("dedup,micro,protocol,whole", [
+    (False, 1, "exact", "auto"), (True, 1, "exact", "auto"), (True, 3, "exact", "auto"), (False, 500, "exact", "auto"),
+    (False, 1, "fixed", "auto"), (True, 1, "fixed", "auto"), (True, 1, "fixed", False), (False, 3, "fixed", "auto"),
+    (True, 50, "fixed", "auto")])
+def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol, whole):
     """micro > 1: the lookups of slice m+1 run on a side stream beside the fused kernel of slice m; 500 slices for
-    333 / 340 samples also exercises empty slices (every rank still takes part in every exchange)"""
+    333 / 340 samples also exercises empty slices (every rank still takes part in every exchange).  (True, 1, "fixed"):
+    13 k lookups of a smaller table -> the whole-shard exchange (all-gather + direct addresses) when `whole` is "auto",
+    the de-duplicated request lists when it is off"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29621 + 2 * int(dedup) + (micro > 1) + 4 * (micro > 100) + 8 * (protocol == "fixed") + 16 * (micro == 50)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, micro, q, protocol)) for r in range(2)]
+    port = (29621 + 2 * int(dedup) + (micro > 1) + 4 * (micro > 100) + 8 * (protocol == "fixed") + 16 * (micro == 50)
+            + 32 * (whole is False))
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dedup, micro, q, protocol, whole)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -68,7 +73,7 @@ def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol
         assert ok, f"rank {rank}: sharded result differs from replicated by {err}"
 
 
-def _worker_in_flight(rank, world, port, q):
+def _worker_in_flight(rank, world, port, q, whole):
     for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -89,7 +94,7 @@ def _worker_in_flight(rank, world, port, q):
         with torch.no_grad():
             want = [m.arm_block(i, v.clone()) for i, v in batches]
             m.shard_embedding()
-            m._shard.dedup, m._shard.protocol = True, "fixed"
+            m._shard.dedup, m._shard.protocol, m._shard.whole_shard = True, "fixed", whole
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             for s in streams:
                 s.wait_stream(torch.cuda.current_stream())
@@ -104,12 +109,13 @@ def _worker_in_flight(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_steps_in_flight_on_two_streams_are_bit_equal_to_replicated():
+@pytest.mark.parametrize("whole", ["auto", False])
+def test_steps_in_flight_on_two_streams_are_bit_equal_to_replicated(whole):
     """bench.py --in-flight 2: consecutive steps alternate between two streams; nothing but the overflow flag is shared
     between steps (the de-duplication workspace is per stream)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_in_flight, args=(r, 2, 29677, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, 2, 29677 + (whole is False), q, whole)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
