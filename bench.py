@@ -74,6 +74,8 @@ def parse():
                          "answer request lists (off)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="N > 1: skip the extra row-sharded measurement of BASELINE.json configs[3] (nfeat 100 M, nemb 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -353,6 +355,51 @@ def main():
     elif a.shard == "rows":
         sharded_overflow = bool(model._shard.overflowed())
 
+    # BASELINE.json configs[3] — nfeat = 100 M, nemb = 64: the table that is row-sharded because of its size (25.6 GB),
+    # 2.5 M lookups per rank and step into it (request lists, no de-duplication to speak of).  Measured beside the
+    # headline at N > 1, under its own watchdog; never touches `value`.
+    big = {"done": False, "err": None}
+    if a.shard == "both" and world > 1 and sharded["done"] and not a.no_config4 and a.nhead == 1:
+        import threading
+
+        def run_big():
+            try:
+                torch.cuda.set_device(local)
+                a4 = argparse.Namespace(**vars(a))
+                a4.nemb, a4.nfeat, a4.shard, a4.regime = 64, 100_000_000, "rows", "fresh"
+                m4 = build_model(a4, dev, rank, world, "fresh")
+                b4 = [make_batch(a4, rank, dev, k)[:2] for k in range(NB)]
+                nfl = max(1, a.in_flight)
+                streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+                for s_ in streams:
+                    s_.wait_stream(torch.cuda.current_stream())
+                turn = [0]
+
+                def step():
+                    k = turn[0]
+                    turn[0] += 1
+                    with torch.no_grad(), torch.cuda.stream(streams[k % nfl]):
+                        return m4.arm_block(b4[k % NB][0], b4[k % NB][1])
+
+                for _ in range(3):
+                    step()
+                steps4 = min(a.steps, 20)
+                ms, _ = timed(step, steps4, sync_all)
+                ts = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                big.update(ms=float(ts.item()), steps=steps4, overflow=bool(m4._shard.overflowed()),
+                           exchange=m4._shard.last_path, in_flight=nfl,
+                           shard_gb=m4._shard.table_local.numel() * 4 / 1e9)
+            except Exception as e:  # noqa: BLE001
+                big["err"] = f"{type(e).__name__}: {e}"
+            big["done"] = True
+
+        th4 = threading.Thread(target=run_big, daemon=True)
+        th4.start()
+        th4.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "180")))
+        if not big["done"]:
+            big["err"] = "timeout: the configs[3] measurement did not complete"
+
     if rank == 0:
         read_b = a.nfield * (8 + 4 + 4 * a.nemb)          # ids int64 + vals + F rows      
         write_b = 4 * O * a.nemb                          # post-BN activations
@@ -443,13 +490,25 @@ def main():
                         f"across xGMI), fused kernel over (rows, perm); overflow flag checked after the timed steps; "
                         f"steps_in_flight > 1: consecutive steps alternate between that many streams, so the row exchange "
                         f"of one step runs under the fused kernel of the previous one"}
+        if big["done"] or big["err"]:
+            if big["err"] or big.get("overflow"):
+                line["config4_row_sharded"] = {"error": big["err"] or "a slot of the fixed-capacity exchange overflowed"}
+            else:
+                line["config4_row_sharded"] = {
+                    "value": world * a.batch * big["steps"] / (big["ms"] * 1e-3), "unit": "samples/s",
+                    "ms_per_step": big["ms"] / big["steps"], "steps": big["steps"], "exchange": big["exchange"],
+                    "steps_in_flight": big["in_flight"], "shard_gb_per_rank": big["shard_gb"],
+                    "note": f"BASELINE.json configs[3]: armnet_1h nfield={a.nfield} nfeat=100000000 nemb=64 nhid={a.nhid} "
+                            f"B={a.batch}/GPU, the 25.6 GB table row-sharded over the {world} ranks (never materialised "
+                            f"whole), fused block per step; every sample needs {(world - 1) / world:.0%} of its "
+                            f"{a.nfield} x 256-byte rows from other ranks"}
         if a.shard == "rows":
             line["row_sharded_overflow"] = sharded_overflow
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             a_head = argparse.Namespace(**vars(a))
             line["cpu_baseline"] = cpu_baseline(a_head, model, ids_cpu, vals_cpu)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if a.shard == "both" and not sharded["done"]:
+    if (a.shard == "both" and not sharded["done"]) or (big["err"] and not big["done"]):
         os._exit(0)                 # a stuck collective: leave without tearing the process group down
     if use_dist:
         dist.destroy_process_group()
