@@ -179,3 +179,29 @@ def test_matrix_core_and_generic_block_match_the_oracle(variant, F, E, K, nhid, 
         assert_close(block.cpu().numpy(), want["x_arm"], TOL, f"{variant} flags={flags}")
         outs.append(block)
     assert torch.isfinite(outs[0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,F,E,K,nhid,alpha", [("gc", 39, 16, 1, 32, 2.0), ("gc", 39, 16, 2, 16, 1.7),
+                                                      ("afn", 39, 16, 1, 32, 0.0), ("afn", 22, 32, 1, 48, 0.0)])
+def test_sibling_modes_at_a_batch_that_fills_the_persistent_grid(variant, F, E, K, nhid, alpha):
+    """B = 20 011 > 8 192: every wave takes several groups, so the software pipeline's steady state (prefetched rows,
+    raw ids two groups ahead, the clamped re-read past the end, a short last group) runs in the sibling modes too"""
+    ctor, m = _grid_model(variant, F, E, K, nhid, alpha, seed=7)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    B = 20011
+    ids = torch.randint(0, ctor["nfeat"], (B, F), generator=g)
+    vals = torch.rand(B, F, generator=g) * 1.2 - 0.1
+    want = _oracle({"variant": variant, "ctor": ctor}, sd, ids.numpy(), vals.numpy())
+    m = m.to(DEV)
+    with torch.no_grad():
+        y = m({"id": ids.to(DEV), "value": vals.clone().to(DEV)})
+        v = vals.clone().to(DEV)
+        block = (m.arm_block if variant == "gc" else m.afn_block)(ids.to(DEV), v)
+        block32 = (m.arm_block if variant == "gc" else m.afn_block)(ids.to(DEV).int(), vals.clone().to(DEV))
+    np.testing.assert_array_equal(v.cpu().numpy(), want["vals_clamped"])
+    assert_close(block.cpu().numpy(), want["x_arm"], TOL, f"{variant} B={B}")
+    assert torch.equal(block, block32)                                   # int32 ids: the same kernel, bit for bit
+    scale = max(1.0, float(np.max(np.abs(want["x_arm"]))))
+    assert rel_err(y.cpu().numpy(), want["logits"]) <= TOL * scale
