@@ -4,32 +4,38 @@
 namespace armnet {
 
 // nemb 4..64 (any, odd too: 16-byte staging chunks at the rows' natural 4-byte alignment); nfield <= 48; neurons <= 1024 (slices of <= 256 per launch)
-// LDS of one block for a slice of `o_slice` neurons (same formula as launch_one): 4 wave tiles + the lane-ready
-// parameters of the slice (the sibling models add a table of < 1 KiB: a shape at the very edge is refused by
-// launch_one and runs on the generic kernel)
-static size_t mfma_lds_bytes(int F, int E, int o_slice) {
+// Waves a CU holds for a slice of `o_slice` neurons (same LDS formula and block-size choice as launch_one; the sibling
+// models add a table of < 1 KiB: a shape at the very edge is refused by launch_one and runs on the generic kernel)
+static int mfma_cu_waves(int F, int E, int o_slice) {
     const int nq = (((F + 3) / 4) + 1) & ~1;
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
     const int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
     const int ntile = (spw * nq + 3) / 4, nt = (o_slice + 15) / 16;
-    return ((size_t)4 * (ntile * 16 * (ep + 4) + 256) + (size_t)nt * (ep / 16) * 256 + (size_t)nt * (nq / 2) * 128 +
-            (size_t)nt * 32) * sizeof(float);
+    const int wps = ep >= 64 ? (nq >= 10 ? 2 : 3) : ep >= 32 ? 3 : 4;        // launch_one's register budget (alpha = 2)
+    const size_t wave_bytes = (size_t)(ntile * 16 * (ep + 4) + 256) * sizeof(float);
+    const size_t param_bytes = ((size_t)nt * (ep / 16) * 256 + (size_t)nt * (nq / 2) * 128 + (size_t)nt * 32) * sizeof(float);
+    int b = 0;
+    const int w = mfma_pick_wpb(wave_bytes, param_bytes, wps, &b);
+    return w * b;
 }
 
-// neurons per launch: as many as possible (each slice re-gathers the rows) while two blocks still fit a CU's LDS —
-// at 256 neurons the parameter copies of a 39-field block leave room for one block (1 wave/SIMD): measured 853 us
-// against 2 x 373 us for two launches of 128
+// neurons per launch: as many as possible (each slice re-gathers the rows) while the CU still holds 3 waves per SIMD —
+// or, where no slice reaches that (nemb = 64), the slice that holds the most
 static int mfma_slice(int F, int E, int O) {
-    int slice = 256;
-    while (slice > 64 && slice / 2 >= 16 && (O > slice / 2) && mfma_lds_bytes(F, E, slice < O ? slice : O) > 80 * 1024)
-        slice /= 2;
-    return slice;
+    int best = 64, best_waves = -1;
+    for (int slice = 256; slice >= 64; slice /= 2) {
+        if (slice / 2 >= O && slice > 64) continue;                      // a smaller slice already covers O
+        int w = mfma_cu_waves(F, E, slice < O ? slice : O);
+        if (w > 12) w = 12;
+        if (w > best_waves) { best = slice; best_waves = w; }
+    }
+    return best;
 }
 
 bool fused_mfma_supports(int F, int E, int O) {
     if (E < 4 || E > 64 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
     const int slice = mfma_slice(F, E, O);
-    return mfma_lds_bytes(F, E, O < slice ? O : slice) <= 160 * 1024;
+    return mfma_cu_waves(F, E, O < slice ? O : slice) > 0;
 }
 
 int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {

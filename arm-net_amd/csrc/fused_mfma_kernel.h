@@ -117,8 +117,15 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 //                 in registers from the tile (gc_arm.py:89); no outer exp (gc_arm.py:92-94);
 //   MODEL_AFN     the tile holds log2(x); no MFMA #1 and no sparse map: the B operand of MFMA #2 is afn.weight with the
 //                 emb_bn scale folded in, the emb_bn shift goes into the bias (afn.py:63-66).
+//
+// Waves per block (blockDim.x / 64: 4, 8 or 12) is a LAUNCH parameter: the waves never talk to each other, they only
+// share the block's parameter copies in LDS.  Few neurons: 4 (several blocks per CU).  Many neurons (>= 128): the
+// parameter copies dominate the LDS, so ONE block of 12 waves per CU keeps 3 waves/SIMD where blocks of 4 would leave 2
+// (or 1 at 256 neurons, which is why such blocks used to be cut into slices that each re-gather the rows).
+constexpr int mfma_max_wpb(int wps) { return wps >= 3 ? 12 : 8; }
+
 template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM>
-__global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
+__global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
     constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
     constexpr int ES = E + 4;                 // LDS row stride (floats)
@@ -138,6 +145,8 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const int wpb = (int)(blockDim.x >> 6);                              // waves per block (launch parameter)
+    const int nthreads = (int)blockDim.x;
     const int c = lane & 15, g = lane >> 4;
     const int F = a.F, O = a.O, Er = a.E;     // Er: real embedding width (<= E)
     const int O_out = a.O_out ? a.O_out : O;  // row stride of `out` in neurons (a slice of a wider block)
@@ -145,7 +154,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     float* xt = lds_all + wave * WAVE_FLOATS;
     float* red = xt + TILE_FLOATS;
     // block-shared, lane-ready parameters (zero-padded in e, f and o)
-    float* p_bq = lds_all + 4 * WAVE_FLOATS;               // [NT][EB][64] f32x4
+    float* p_bq = lds_all + wpb * WAVE_FLOATS;             // [NT][EB][64] f32x4
     float* p_vv = p_bq + NT * EB * 64 * 4;                 // [NT][NP][64] f32x2
     float* p_bn = p_vv + NT * NP * 64 * 2;                 // [NT][16] f32x2 {scale, shift}
     float* p_x = p_bn + NT * 32;                           // GC-ARM: [NQ][4] f32x2 emb_bn {scale, shift} of field 4j+g; AFN: [NT][16] bias * log2(e)
@@ -154,8 +163,8 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     const int Bi = (int)a.B;
     const uint32_t BF = (uint32_t)Bi * (uint32_t)F;
     const int ngroups = (Bi + SPW - 1) / SPW;
-    const int nwaves = (int)gridDim.x * 4;
-    int grp = (int)blockIdx.x * 4 + wave;
+    const int nwaves = (int)gridDim.x * wpb;
+    int grp = (int)blockIdx.x * wpb + wave;
 
     // ---- group-invariant staging geometry: which (sample, field) each staging lane fetches -------
     const int chunk = lane % CH;
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
     };
 
     if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
-    for (int i = threadIdx.x; MODEL != MODEL_AFN && i < NT * EB * 64; i += 256) {
+    for (int i = threadIdx.x; MODEL != MODEL_AFN && i < NT * EB * 64; i += nthreads) {
         const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
         const int o = 16 * nt + (l & 15);
         const int e0 = 16 * kb + 4 * (l >> 4);
@@ -300,7 +309,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
                 if (e0 + r < Er) v[r] = a.q_fold[(size_t)o * Er + e0 + r];
         *reinterpret_cast<f32x4*>(p_bq + i * 4) = v;
     }
-    for (int i = threadIdx.x; i < NT * NP * 64; i += 256) {
+    for (int i = threadIdx.x; i < NT * NP * 64; i += nthreads) {
         const int l = i & 63, jp = (i >> 6) % NP, nt = (i >> 6) / NP;
         const int o = 16 * nt + (l & 15);
         const int f0 = 4 * (2 * jp) + (l >> 4), f1 = f0 + 4;
@@ -315,11 +324,11 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
         *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
     }
     if constexpr (MODEL == MODEL_GC_ARM) {
-        for (int i = threadIdx.x; i < NQ * 4; i += 256)      // pad fields: 0 * exp(0) + 0 = 0
+        for (int i = threadIdx.x; i < NQ * 4; i += nthreads)      // pad fields: 0 * exp(0) + 0 = 0
             *reinterpret_cast<f32x2*>(p_x + i * 2) = i < F ? f32x2{a.emb_scale[i], a.emb_shift[i]} : f32x2{0.f, 0.f};
     }
     if constexpr (MODEL == MODEL_AFN) {
-        for (int o = threadIdx.x; o < NT * 16; o += 256) {
+        for (int o = threadIdx.x; o < NT * 16; o += nthreads) {
             float bsum = 0.f;
             if (o < O) {
                 bsum = a.lin_bias[o];
@@ -328,7 +337,7 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
             p_x[o] = bsum * kLog2e;
         }
     }
-    for (int i = threadIdx.x; i < NT * 16; i += 256)
+    for (int i = threadIdx.x; i < NT * 16; i += nthreads)
         *reinterpret_cast<f32x2*>(p_bn + i * 2) = i < O ? f32x2{a.bn_scale[i], a.bn_shift[i]} : f32x2{0.f, 0.f};
     __syncthreads();
     if (grp >= ngroups) return;
@@ -764,6 +773,22 @@ __global__ void __launch_bounds__(256, WPS) fused_mfma_kernel(FusedArgs a) {
 #define ARMNET_WPS 4
 #endif
 
+// Waves per block for a block whose waves need `wave_bytes` of LDS each and share `param_bytes`: the choice (4, 8, 12;
+// at most mfma_max_wpb(wps)) that puts the most waves on a CU — blocks per CU bounded by the LDS and by wps waves per
+// SIMD —, the smaller block on a tie.  Returns 0 when not even 4 waves fit; *blocks_per_cu for the persistent grid.
+static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, int* blocks_per_cu) {
+    int best = 0, best_waves = 0;
+    for (int w = 4; w <= mfma_max_wpb(wps); w += 4) {
+        const size_t lds = (size_t)w * wave_bytes + param_bytes;
+        if (lds > 160 * 1024) break;
+        int b = (int)(160 * 1024 / lds);
+        if (b > wps * 4 / w) b = wps * 4 / w;
+        if (b < 1) b = 1;
+        if (b * w > best_waves) { best = w; best_waves = b * w; if (blocks_per_cu) *blocks_per_cu = b; }
+    }
+    return best;
+}
+
 // SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
 // nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
 template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
@@ -778,15 +803,26 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
                         : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
-    const size_t lds = ((size_t)4 * (NTILE * 16 * (E + 4) + 256) + (size_t)NT * (E / 16) * 256 +
-                        (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32 +
-                        (MODEL == MODEL_GC_ARM ? (size_t)NQ * 8 : MODEL == MODEL_AFN ? (size_t)NT * 16 : 0)) * sizeof(float);
-    if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    const size_t wave_bytes = (size_t)(NTILE * 16 * (E + 4) + 256) * sizeof(float);
+    const size_t param_bytes = ((size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 + (size_t)NT * 32 +
+                                (MODEL == MODEL_GC_ARM ? (size_t)NQ * 8 : MODEL == MODEL_AFN ? (size_t)NT * 16 : 0)) * sizeof(float);
+    int per_cu = 0;
+    int wpb = mfma_pick_wpb(wave_bytes, param_bytes, WPS, &per_cu);
+    if (wpb == 0) return ARMNET_ERR_UNSUPPORTED;
+#ifdef ARMNET_DEV_FLAGS
+    if (const char* fw = getenv("ARMNET_FORCE_WPB")) {          // developer knob: waves per block
+        const int w = atoi(fw);
+        if (w >= 4 && w <= mfma_max_wpb(WPS) && (size_t)w * wave_bytes + param_bytes <= 160 * 1024) {
+            wpb = w;
+            per_cu = (int)(160 * 1024 / ((size_t)w * wave_bytes + param_bytes));
+            if (per_cu > WPS * 4 / w) per_cu = WPS * 4 / w;
+            if (per_cu < 1) per_cu = 1;
+        }
+    }
+#endif
+    const size_t lds = (size_t)wpb * wave_bytes + param_bytes;
     const int64_t ngroups = (a.B + SPW - 1) / SPW;
-    const int64_t blocks = (ngroups + 3) / 4;
-    int per_cu = (int)(160 * 1024 / lds);
-    if (per_cu > WPS) per_cu = WPS;
-    if (per_cu < 1) per_cu = 1;
+    const int64_t blocks = (ngroups + wpb - 1) / wpb;
     const int64_t resident = (int64_t)device_cu_count() * per_cu;   // blocks the chip holds at once
     // persistent grid-stride waves: the software pipeline's prologue is paid once per wave
     int64_t want = blocks < resident ? blocks : resident;
@@ -801,7 +837,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    kern<<<(int)want, 256, lds, st>>>(a);
+    kern<<<(int)want, 64 * wpb, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
