@@ -274,7 +274,9 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-constexpr int kWaves = 8;                 // waves per block: 256 samples share one pass of the weight stream
+// Waves per block (kWaves, template parameter): 32 * kWaves samples share one pass of the weight stream.  8 at large
+// batches (256 blocks of 256 samples fill the chip at B = 65 536), 4 when the batch would otherwise leave CUs idle
+// (launch_mlp).
 constexpr int kWRing = 3;                 // weight stages resident in LDS (consumed | landing | requested)
 constexpr int kXRing = 3;                 // activation tiles per wave in LDS (read | landing | requested)
 
@@ -286,8 +288,8 @@ __device__ unsigned long long g_mlp_phase[8];
 #define MLP_PHASE(i) do {} while (0)
 #endif
 
-template <int NT>
-__global__ void __launch_bounds__(64 * kWaves, 2) mlp_head_kernel(MlpArgs a) {
+template <int NT, int kWaves>
+__global__ void __launch_bounds__(64 * kWaves, kWaves >= 8 ? 2 : 1) mlp_head_kernel(MlpArgs a) {
     constexpr int TG = mlp_tg(NT), NG = NT / TG, KPS = mlp_kps(NT), NS2 = 2 * NT / KPS;
     constexpr int ST1 = NT * 3 * 1024, ST2 = KPS * TG * 3 * 1024;
     static_assert(ST2 <= ST1, "a layer-2 stage must fit a ring slot");
@@ -543,12 +545,12 @@ __global__ void __launch_bounds__(64 * kWaves, 2) mlp_head_kernel(MlpArgs a) {
     }
 }
 
-template <int NT>
-static int launch_mlp(const MlpArgs& a, hipStream_t st) {
+template <int NT, int kWaves>
+static int launch_mlp_kw(const MlpArgs& a, hipStream_t st) {
     static_assert(mlp_kps(NT) * mlp_tg(NT) <= NT, "a layer-2 stage must fit a ring slot");
     const size_t lds = (size_t)kWRing * NT * 3 * 1024 + ((((size_t)3 * NT * 32 + 4) * sizeof(float) + 15) & ~(size_t)15) +
                        (size_t)kWaves * kXRing * 2048;
-    auto kern = mlp_head_kernel<NT>;
+    auto kern = mlp_head_kernel<NT, kWaves>;
     if (lds > 64 * 1024)
         ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -556,6 +558,19 @@ static int launch_mlp(const MlpArgs& a, hipStream_t st) {
     kern<<<(int)blocks, 64 * kWaves, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
+}
+
+// Waves per block for a batch.  A block runs for about the same time whatever the batch (it streams every weight), so
+// 4-wave blocks (128 samples, one wave per SIMD, no spills at 512 registers) win as long as ALL of them are resident
+// at once — one per CU: B <= 128 * CUs = 32 768 on MI355X (65-80 us against 94-107 us for 8-wave blocks) —; beyond
+// that the 8-wave blocks' halved weight traffic per sample wins (B = 65 536: 147 against 171 us).
+template <int NT>
+static int launch_mlp(const MlpArgs& a, hipStream_t st) {
+    int kw = (a.B + 127) / 128 <= device_cu_count() ? 4 : 8;
+#if defined(ARMNET_DEV_FLAGS) || defined(ARMNET_MLP_KW_ENV)
+    if (const char* e = getenv("ARMNET_MLP_KW")) kw = atoi(e);          // developer knob
+#endif
+    return kw == 4 ? launch_mlp_kw<NT, 4>(a, st) : launch_mlp_kw<NT, 8>(a, st);
 }
 
 }  // namespace armnet

@@ -40,6 +40,26 @@ HEADS = [(512, 2, 256), (2048, 2, 256), (704, 2, 256), (320, 2, 32), (130, 1, 16
          (512, 2, 128), (17, 4, 8), (640, 2, 200), (1280, 1, 256), (390, 3, 16)]
 
 
+# the kernel runs with 4-wave blocks (128 samples) while all of them fit the chip at once (B <= 32 768) and with 8-wave
+# blocks (256 samples) beyond: both sides of the switch, ragged last blocks
+BIG = [(512, 2, 256, 33001), (512, 2, 256, 32768), (320, 2, 32, 40007), (130, 1, 16, 33001), (640, 2, 200, 33001),
+       (17, 4, 8, 50000), (100, 3, 64, 32769)]
+
+
+@pytest.mark.parametrize("K0,nlayers,nhid,B", BIG)
+def test_mlp_head_matches_float64_evaluation_on_both_block_sizes(K0, nlayers, nhid, B):
+    m = _make_head(K0, nlayers, nhid, seed=K0 + nhid).to(DEV)
+    g = torch.Generator().manual_seed(B)
+    x = (torch.rand(B, K0, generator=g) * 3.0 - 1.0).to(DEV)
+    want = _ref64(m, x).cpu().numpy()
+    with torch.no_grad():
+        got = m(x).cpu().numpy()
+        small = torch.cat([m(x[i:i + 8192]) for i in range(0, B, 8192)]).cpu().numpy()   # the 4-wave kernel, in pieces
+    e = elem_excess(got, want, TOL)
+    assert e <= 1.0, f"worst element at {e:.3f} x the 1e-5 bar"
+    np.testing.assert_array_equal(got, small)            # same arithmetic per sample whatever the block size
+
+
 @pytest.mark.parametrize("K0,nlayers,nhid", HEADS)
 @pytest.mark.parametrize("B", [1, 37, 1000])
 def test_mlp_head_matches_float64_evaluation(K0, nlayers, nhid, B):
