@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--nemb", type=int, default=16)
     ap.add_argument("--nhid", type=int, default=32)
     ap.add_argument("--nhead", type=int, default=1, help=">1 selects models.armnet (multi-head)")
+    ap.add_argument("--ensemble", action="store_true",
+                    help="build the model with the DNN ensemble branch (BASELINE.json configs[4]); it only enters full_forward")
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--shard", choices=["replicate", "rows", "both"], default=None,
                     help="replicate = every rank holds the table (no collective); rows = table row-sharded over "
@@ -91,10 +93,10 @@ def build_model(a, device, rank=0, world=1, regime=None):
     nfeat_mod = 16 if a.shard == "rows" else a.nfeat
     if a.nhead == 1:
         from models.armnet_1h import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, False, 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, bool(a.ensemble), 2, 256)
     else:
         from models.armnet import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, False, 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, bool(a.ensemble), 2, 256)
     if regime == "stress":
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():
@@ -469,7 +471,9 @@ def main():
             "regimes": {r: regime_obj(r) for r in regimes},
             "full_forward": {"value": world * a.batch * a.steps / (full_wall_ms * 1e-3), "unit": "samples/s",
                              "ms_per_step": full_wall_ms / a.steps,
-                             "note": f"fused block + MLP head 2x256 to logits ({model.mlp.eval_path()})"},
+                             "note": f"fused block + MLP head 2x256 to logits ({model.mlp.eval_path()})"
+                                     + (" + DNN ensemble branch (second table lookup, deep MLP 2x256 on the HIP head, "
+                                        "ensemble Linear)" if a.ensemble else "")},
         }
         if a.shard == "both":
             line["replicated"] = {"value": replicated_value, "unit": "samples/s", "ms_per_step": replicated_ms,

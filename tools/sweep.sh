@@ -13,6 +13,7 @@ run --nhead 4 --regime stress --alpha 1.7
 run --nemb 64 --nfeat 10000000
 run --nemb 64 --nfeat 100000000 --shard rows
 run --nhead 4 --nemb 32 --nfield 22 --nfeat 2000000 --batch 131072
+run --nhead 4 --nemb 32 --nfield 22 --nfeat 2000000 --batch 131072 --ensemble
 run --shard rows
 run --batch 8192
 run --batch 262144
