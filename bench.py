@@ -93,10 +93,10 @@ def build_model(a, device, rank=0, world=1, regime=None):
     nfeat_mod = 16 if a.shard == "rows" else a.nfeat
     if a.nhead == 1:
         from models.armnet_1h import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, bool(a.ensemble), 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, bool(getattr(a, "ensemble", False)), 2, 256)
     else:
         from models.armnet import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, bool(a.ensemble), 2, 256)
+        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, bool(getattr(a, "ensemble", False)), 2, 256)
     if regime == "stress":
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():
