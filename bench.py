@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--regime", choices=["fresh", "stress", "both"], default="both",
                     help="fresh = the reference's initialisers (what `value` reports); stress = SURVEY §8c "
                          "sparse-support weights; both = measure both, `value` from fresh")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed run of the step before the warm-up steps, so that the device clocks have settled")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct (ids, vals, out) batches cycled through by the steps (working set > 256 MiB MALL)")
     ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step")
@@ -131,6 +133,20 @@ def make_batch(a, rank, device, k=0):
         ids = (a.nfeat ** u - 1).clamp_(0, a.nfeat - 1).to(torch.int64)
     vals = torch.rand(a.batch, a.nfield, generator=g)
     return ids.to(device), vals.to(device), ids, vals
+
+
+def settle_clocks(fn, ms):
+    """Run the step, untimed, for about `ms` milliseconds before the W warm-up steps.  A GPU that was idle takes some
+    50 ms of sustained load before its clocks settle (measured: the same whole forward takes 230 us per batch in the first
+    30 ms after idle and 204 us from then on); the K timed steps are a few milliseconds, so without this they would
+    measure the ramp of a cold device instead of the steady state of a serving loop."""
+    if ms <= 0:
+        return
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(16):
+            fn()
+        torch.cuda.synchronize()
 
 
 def timed(fn, steps, sync_all):
@@ -257,6 +273,7 @@ def main():
 
     regimes = ["fresh", "stress"] if a.regime == "both" else [a.regime]
     res, models = {}, {}
+    cold_ms = [None]
     for regime in regimes:
         model = models[regime] = build_model(a, dev, rank, world, regime)
         turn = [0]
@@ -273,19 +290,26 @@ def main():
             with torch.no_grad():
                 return model({"id": batches[k][0], "value": batches[k][1]})
 
+        if a.settle_ms > 0 and regime == regimes[0]:
+            # the same W + K steps from a cold device, for the record (`cold_start` in the line)
+            for _ in range(a.warmup):
+                step_block()
+            cold_ms[0] = timed(step_block, a.steps, sync_all)[0]
+        settle_clocks(step_block, a.settle_ms)
         for _ in range(a.warmup):
             step_block()
         wall_ms, ev_ms = timed(step_block, a.steps, sync_all)
+        settle_clocks(step_full, a.settle_ms)
         for _ in range(a.warmup):
             step_full()
         full_wall_ms, _ = timed(step_full, a.steps, sync_all)
-        t = torch.tensor([wall_ms, ev_ms, full_wall_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall_ms, ev_ms, full_wall_ms, cold_ms[0] or 0.0], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res[regime] = t.tolist()
     head = regimes[0]                                     # `value` regime: fresh (random-init weights) unless --regime
     model = models[head]
-    wall_ms, ev_ms, full_wall_ms = res[head]
+    wall_ms, ev_ms, full_wall_ms, cold_wall_ms = res[head]
     sharded_overflow = None
 
     # Row-sharded variant: same model, same batches, the table row-sharded over the ranks and fetched by all-to-all.
@@ -310,6 +334,7 @@ def main():
                 # process group's own stream; the timed region ends with a device-wide synchronize.  Measured with one
                 # step in flight first, then with a.in_flight: the faster one is the row-sharded number, both are reported
                 # (and a failure of the second mode keeps the first).
+                n_settle = int(min(2000, max(0.0, a.settle_ms) / max(1e-3, 2.0 * res[head][0] / a.steps)))
                 for nfl in sorted({1, max(1, a.in_flight)}):
                     try:
                         streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
@@ -324,6 +349,10 @@ def main():
                             with torch.no_grad(), torch.cuda.stream(s_):
                                 return model.arm_block(batches[k][0], batches[k][1])
 
+                        # clocks: every step holds collectives, so the untimed pre-run is a step COUNT that is the same
+                        # on every rank (from the all-reduced replicated step time), not a time budget
+                        for _ in range(n_settle):
+                            step_sharded()
                         for _ in range(a.warmup):
                             step_sharded()
                         ms, _ = timed(step_sharded, a.steps, sync_all)
@@ -389,7 +418,7 @@ def main():
                     with torch.no_grad(), torch.cuda.stream(streams[k % nfl]):
                         return m4.arm_block(b4[k % NB][0], b4[k % NB][1])
 
-                for _ in range(3):
+                for _ in range(3 + (25 if a.settle_ms > 0 else 0)):     # fixed count (collectives inside): ~50-100 ms
                     step()
                 steps4 = min(a.steps, 20)
                 ms, _ = timed(step, steps4, sync_all)
@@ -415,7 +444,7 @@ def main():
         flops = 4 * O * a.nfield * a.nemb * a.batch       # folded formulation: the two contractions
 
         def roof(regime):
-            w_ms, e_ms, f_ms = res[regime]
+            w_ms, e_ms, f_ms = res[regime][:3]
             k_ms = e_ms / a.steps                         # back-to-back launches of ONE kernel per step
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             tfl = flops / (k_ms * 1e-3) / 1e12
@@ -434,7 +463,7 @@ def main():
                                      "MFMA roofline binds: see fractions"}
 
         def regime_obj(regime):
-            w_ms, e_ms, f_ms = res[regime]
+            w_ms, e_ms, f_ms = res[regime][:3]
             r = roof(regime)
             return {"value": world * a.batch * a.steps / (w_ms * 1e-3), "unit": "samples/s",
                     "ms_per_step": w_ms / a.steps, "kernel_ms": r["kernel_ms"], "roofline_frac_hbm": r["frac"],
@@ -465,8 +494,9 @@ def main():
                                    f"alpha={a.alpha} B={a.batch}/GPU, ids {a.ids} int64, weights {head}-init "
                                    f"(random-init), eval mode; steps rotate over {NB} distinct batches "
                                    f"(ids+vals+out = {ws_mb:.0f} MB per rotation > 256 MiB Infinity Cache; only "
-                                   f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read)",
-                       "global_batch": world * a.batch, "parallelism": parallelism},
+                                   f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read); device clocks settled "
+                                   f"by {a.settle_ms:g} ms of the same step, untimed, before the warm-up steps",
+                       "global_batch": world * a.batch, "parallelism": parallelism, "clock_settle_ms": a.settle_ms},
             "roofline": roof(head),
             "regimes": {r: regime_obj(r) for r in regimes},
             "full_forward": {"value": world * a.batch * a.steps / (full_wall_ms * 1e-3), "unit": "samples/s",
@@ -475,6 +505,13 @@ def main():
                                      + (" + DNN ensemble branch (second table lookup, deep MLP 2x256 on the HIP head, "
                                         "ensemble Linear)" if a.ensemble else "")},
         }
+        if cold_wall_ms:
+            line["cold_start"] = {
+                "value": world * a.batch * a.steps / (cold_wall_ms * 1e-3), "unit": "samples/s",
+                "ms_per_step": cold_wall_ms / a.steps,
+                "note": f"the same {a.warmup} + {a.steps} steps taken right after process start, before the {a.settle_ms:g} ms "
+                        f"untimed pre-run that lets the device clocks settle (`value` is the steady state of a serving "
+                        f"loop; a device coming out of idle runs the same kernel about 20 % slower for its first ~50 ms)"}
         if a.shard == "both":
             line["replicated"] = {"value": replicated_value, "unit": "samples/s", "ms_per_step": replicated_ms,
                                   "note": "table on every rank, batch split, no data-path collective"}

@@ -15,9 +15,12 @@ batches = [(torch.randint(0, nfeat, (B, F), generator=g).to(dev), torch.rand(B, 
 
 
 def timeit(fn, n=40):
-    for k in range(4):
-        fn(k)
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:                   # let the device clocks settle (cold: ~20 % slower)
+        for k in range(8):
+            fn(k)
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for k in range(n):

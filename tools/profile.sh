@@ -7,9 +7,13 @@ OUT=$1; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/gpurun_out/$OUT"
 cd /tmp && export TMPDIR=/tmp
+# PMC_EXTRA: extra arguments for the command in the counter passes only (counters do not depend on the clocks, so
+# bench.py's untimed clock-settling pre-run — thousands of dispatches — is switched off there: --settle-ms 0)
 run() { # name, extra args...
   local name=$1; shift
-  rocprofv3 "$@" --kernel-trace --output-format csv -d "$ROOT/gpurun_out/$OUT/$name" -- "${CMD[@]}" > "$ROOT/gpurun_out/$OUT/$name.log" 2>&1
+  local extra=()
+  if [ "$name" != trace ] && [ -n "${PMC_EXTRA:-}" ]; then read -r -a extra <<< "$PMC_EXTRA"; fi
+  rocprofv3 "$@" --kernel-trace --output-format csv -d "$ROOT/gpurun_out/$OUT/$name" -- "${CMD[@]}" "${extra[@]}" > "$ROOT/gpurun_out/$OUT/$name.log" 2>&1
 }
 CMD=("$@")
 run trace --stats

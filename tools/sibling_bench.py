@@ -15,9 +15,12 @@ vals = torch.rand(B, F, generator=g).to(dev)
 
 
 def timeit(fn, n=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:                   # let the device clocks settle (cold: ~20 % slower)
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
