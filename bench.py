@@ -335,6 +335,8 @@ def main():
                 # step in flight first, then with a.in_flight: the faster one is the row-sharded number, both are reported
                 # (and a failure of the second mode keeps the first).
                 n_settle = int(min(2000, max(0.0, a.settle_ms) / max(1e-3, 2.0 * res[head][0] / a.steps)))
+                if backend != "nccl":
+                    n_settle = min(n_settle, 10)             # host-staged developer path: a step takes tens of ms
                 for nfl in sorted({1, max(1, a.in_flight)}):
                     try:
                         streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
