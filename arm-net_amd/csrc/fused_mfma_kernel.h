@@ -256,18 +256,22 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
             const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
             const bool short_grp = gc * SPW + SPW > Bi;              // wave-uniform, true at most once
             const char* ids_g = reinterpret_cast<const char*>(a.ids) + (size_t)e0 * (SRC == 0 ? 8 : 4);
+            auto body = [&](auto is_short) {                         // two copies: the common one has no per-lane select
 #pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
-                if constexpr (SRC == 0) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(ids_g + (o << 1));
-                    raw_lo[n] = w.x;
-                    raw_hi[n] = w.y;
-                } else {
-                    raw_lo[n] = *reinterpret_cast<const uint32_t*>(ids_g + o);
-                    raw_hi[n] = 0u;
+                for (int n = 0; n < NI; ++n) {
+                    const uint32_t o = decltype(is_short)::value ? lane_off(n, true) : off4[n];
+                    if constexpr (SRC == 0) {
+                        const uint2 w = *reinterpret_cast<const uint2*>(ids_g + (o << 1));
+                        raw_lo[n] = w.x;
+                        raw_hi[n] = w.y;
+                    } else {
+                        raw_lo[n] = *reinterpret_cast<const uint32_t*>(ids_g + o);
+                        raw_hi[n] = 0u;
+                    }
                 }
-            }
+            };
+            if (__builtin_expect(short_grp, 0)) body(std::true_type{});
+            else body(std::false_type{});
         }
     };
     auto issue_rows_vals = [&](int gidx) {
@@ -283,19 +287,23 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 if (bad && chunk == 0) atomicOr(a.id_status, 1);
             }
         }
+        auto body = [&](auto is_short) {                             // two copies: the common one has no per-lane select
 #pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            const uint32_t o = short_grp ? lane_off(n, true) : off4[n];
-            val_cur[n] = *reinterpret_cast<const float*>(vals_g + o);
-            const char* src;
-            if constexpr (FROM_ROWS) {
-                src = row_base + (size_t)(e0 + (o >> 2)) * row_bytes;
-            } else {
-                const uint32_t id = min(raw_lo[n], id_max) & id_mask;   // memory-safe even when unchecked
-                src = row_base + (size_t)id * row_bytes;
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t o = decltype(is_short)::value ? lane_off(n, true) : off4[n];
+                val_cur[n] = *reinterpret_cast<const float*>(vals_g + o);
+                const char* src;
+                if constexpr (FROM_ROWS) {
+                    src = row_base + (size_t)(e0 + (o >> 2)) * row_bytes;
+                } else {
+                    const uint32_t id = min(raw_lo[n], id_max) & id_mask;   // memory-safe even when unchecked
+                    src = row_base + (size_t)id * row_bytes;
+                }
+                rows_cur[n] = *reinterpret_cast<const RowTU*>(src);
             }
-            rows_cur[n] = *reinterpret_cast<const RowTU*>(src);
-        }
+        };
+        if (__builtin_expect(short_grp, 0)) body(std::true_type{});
+        else body(std::false_type{});
     };
 
     if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
