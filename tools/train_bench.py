@@ -21,9 +21,11 @@ def main():
         loss = lossf(m({"id": ids, "value": vals}), y)
         opt.zero_grad(); loss.backward(); opt.step()
         return loss
-    for _ in range(3): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 10
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < 0.2:                     # warm-up that also lets the device clocks settle
+        step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
     for _ in range(n): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     # forward+backward of the block alone
@@ -39,8 +41,10 @@ def main():
     from armnet_hip.modules import GraphedTrainStep
     opt2 = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
     gstep = GraphedTrainStep(m, opt2, lossf, ids, vals, y)
-    for _ in range(3): gstep(ids, vals, y)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < 0.2:
+        gstep(ids, vals, y); torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(n): gstep(ids, vals, y)
     torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / n
     print(f"B={B} alpha={alpha}: graphed train step {dt3*1e3:.2f} ms ({B/dt3/1e3:.0f} k samples/s)")
