@@ -52,6 +52,10 @@ def test_single_gpu_line_has_the_contract_keys_and_both_objects():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "samples/s" and c["sample"]
     assert set(d["regimes"]) == {"fresh", "stress"}
+    # steady state is `value`; the cold-start run of the same steps and the two-batches-in-flight variant ride along
+    assert d["config"]["clock_settle_ms"] > 0 and d["cold_start"]["value"] > 0
+    fl = d["batches_in_flight"]
+    assert fl["n"] == 2 and fl["value"] > 0 and fl["full_forward_samples_per_s"] > 0
 
 
 @pytest.mark.gpu
