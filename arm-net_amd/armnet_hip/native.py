@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define ARMNET_ABI_VERSION 1
+/* 2: round-2 additions (prediction head, GC-ARM / AFN entry points, fixed-capacity and whole-shard routing helpers);
+ * everything of version 1 is unchanged */
+#define ARMNET_ABI_VERSION 2
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
