@@ -11,7 +11,7 @@ static int mfma_cu_waves(int F, int E, int o_slice) {
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
     const int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
     const int ntile = (spw * nq + 3) / 4, nt = (o_slice + 15) / 16;
-    const int wps = ep >= 64 ? (nq >= 10 ? 2 : 3) : ep >= 32 ? 3 : 4;        // launch_one's register budget (alpha = 2)
+    const int wps = ep >= 64 ? (nq >= 10 ? 2 : 3) : (ep >= 32 || spw * nq >= 16) ? 3 : 4;   // launch_one's register budget (alpha = 2)
     const size_t wave_bytes = (size_t)(ntile * 16 * (ep + 4) + 256) * sizeof(float);
     const size_t param_bytes = ((size_t)nt * (ep / 16) * 256 + (size_t)nt * (nq / 2) * 128 + (size_t)nt * 32) * sizeof(float);
     int b = 0;
