@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     // at the final threshold), which saves the two transcendentals per element of a final pass
                     // alpha = 2 with a 168-register budget (<= 3 waves/SIMD): the clamped differences of the last evaluation
                     // are kept as well, which saves their recomputation in the weight pass
-                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || (MODE == SOLVE_MICHELOT && WPS <= 3);
+                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && WPS <= 3);
                     f32x2 pkeep[KEEP ? SPW * NP : 1];
                     for (int it = 0; it < kNewtonMaxIter; ++it) {
                         wave_lds_fence();
@@ -628,6 +628,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                                 } else if constexpr (MODE == SOLVE_NEWTON15) {
                                     sv = t * t;
                                     dv = t;
+                                    if constexpr (KEEP) pkeep[s * NP + jp] = sv;
                                 } else {
                                     f32x2 u;   // t^(r-1); log2(0) = -inf -> exp2(-inf) = 0 (r > 1)
                                     u[0] = __builtin_amdgcn_exp2f(rm1 * __builtin_amdgcn_logf(t[0]));
@@ -815,7 +816,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
                         // alpha = 2, many fields: 3 waves/SIMD run as fast as 4 (measured with padded LDS: 92.7 vs 93.6 us)
                         // and the 168-register budget holds the last evaluation's clamped differences, so the weight pass
                         // does not recompute them: 88.1 -> 85.5 us.  Few fields (nfield = 10, 256 neurons): 4 is 7 % faster.
-                        : (MODE == SOLVE_MICHELOT && SPW * NQ >= 16) ? 3
+                        : ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && SPW * NQ >= 16) ? 3
                         : ARMNET_WPS;
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
