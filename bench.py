@@ -143,10 +143,20 @@ def settle_clocks(fn, ms):
     if ms <= 0:
         return
     t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(16):
+    best, stale = None, 0
+    while True:             # at least `ms`, then until 8 consecutive chunks of 32 steps brought no new best time (> 1 %)
+        t1 = time.perf_counter()
+        for _ in range(32):
             fn()
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if best is None or dt < 0.99 * best:
+            best, stale = dt, 0
+        else:
+            stale += 1
+        elapsed = (time.perf_counter() - t0) * 1e3
+        if (elapsed >= ms and stale >= 8) or elapsed >= 10 * ms:
+            return
 
 
 def timed(fn, steps, sync_all):
