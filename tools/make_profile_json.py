@@ -37,7 +37,7 @@ def main(prof_dir, gs_log, tag):
         "workload": f"nfield={F} nemb={E} nhid={O} nhead=1 B={B} alpha=2.0 ids=uniform regime=fresh rotate=4",
         "kernel_src_sha": bench.kernel_src_sha(),
         "source": f"profiles/{tag}_bench_n1_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                  f"{n1}/{n2} dispatches of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --regime fresh`)",
+                  f"{n1}/{n2} dispatches of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --regime fresh --in-flight 1 --settle-ms 0`)",
         "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
         "fetch_bytes_raw": fetch_kib * 1024, "write_bytes": write_kib * 1024,
         "stream_halving_correction_bytes": stream // 2,
