@@ -539,3 +539,28 @@ def test_shard_pad_route_kernel_contract(R, dedup, cap_factor):
         np.testing.assert_array_equal(sp[pp], idn // R)                # and holds its local row index
         for o in range(R):                                             # unused entries: index 0
             assert (sp[o * cap + c[o]: (o + 1) * cap] == 0).all()
+
+
+@pytest.mark.gpu
+def test_forwards_in_flight_give_the_sequential_results():
+    """armnet_hip.serving.InFlight: consecutive batches on alternating streams, bit-equal to one-at-a-time execution"""
+    from armnet_hip.serving import InFlight
+    meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
+    c = meta["ctor"]
+    m = build_model(meta, sd, DEV)
+    m.check_ids = False
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randint(0, c["nfeat"], (3000 + 17 * k, c["nfield"]), generator=g).to(DEV),
+                (torch.rand(3000 + 17 * k, c["nfield"], generator=g) * 1.2 - 0.1).to(DEV)) for k in range(7)]
+    with torch.no_grad():
+        want = [m({"id": i, "value": v.clone()}) for i, v in batches]
+    for n in (1, 2, 3):
+        fl = InFlight(m, n=n)
+        hs = [fl.submit(i, v.clone()) for i, v in batches]
+        got = [fl.result(h) for h in hs]
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), n
+    blk = InFlight(m, n=2, call="arm_block")
+    y = blk.result(blk.submit(batches[0][0], batches[0][1].clone()))
+    with torch.no_grad():
+        assert torch.equal(y, m.arm_block(batches[0][0], batches[0][1].clone()))
