@@ -103,7 +103,7 @@ class RowShardedTable:
         self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
         self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
         self.whole_shard = "auto" # fixed protocol: all-gather the shards when the de-duplicated slot would be the whole
-                                  # shard anyway ("auto"), never (False)
+                                  # shard anyway ("auto"), always (True), never (False)
         self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces)
         self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
         self.table_local = table_local
@@ -168,7 +168,7 @@ class RowShardedTable:
         # size for good with `slot_lookups`
         cap = self.capacity(int(getattr(self, "slot_lookups", None) or max(n, 1)), dedup)
         L = (self.nfeat + R - 1) // R
-        if dedup and cap >= L and self.whole_shard == "auto":
+        if self.whole_shard is True or (self.whole_shard == "auto" and dedup and cap >= L):
             self.last_path = "whole_shards"
             return self._lookup_whole_shards(flat, id_status)
         self.last_path = "fixed"
