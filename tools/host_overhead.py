@@ -1,4 +1,4 @@
-import sys, os, time
+import sys, time
 sys.path.insert(0, "/root/repo/arm-net_amd"); sys.path.insert(0, "/root/repo")
 import torch
 from models.armnet_1h import ARMNetModel

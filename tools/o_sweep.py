@@ -4,7 +4,6 @@ import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "arm-net_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
-from armnet_hip import native
 from models.armnet import ARMNetModel
 from models.afn import AFNModel
 

@@ -5,7 +5,6 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
-import numpy as np
 import torch
 from golden_util import load, model_cases
 from model_util import build_model
