@@ -1,5 +1,8 @@
+"""Host time per arm_block call (ctypes + guards) and a cProfile of it."""
 import sys, time
-sys.path.insert(0, "/root/repo/arm-net_amd"); sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "arm-net_amd")); sys.path.insert(0, ROOT)
 import torch
 from models.armnet_1h import ARMNetModel
 dev = "cuda:0"

@@ -1,5 +1,8 @@
+"""torch.profiler view of a few whole forwards (kernels, copies, host ops)."""
 import sys
-sys.path.insert(0, "/root/repo/arm-net_amd"); sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "arm-net_amd")); sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import profile, ProfilerActivity
 from models.armnet_1h import ARMNetModel
