@@ -405,7 +405,7 @@ def main():
 
         th = threading.Thread(target=run_sharded, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "180")))
+        th.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "120")))
         if not sharded["done"]:
             sharded["err"] = "timeout: the row-sharded measurement did not complete (collective hang?)"
     sharded_ms, sharded_err = sharded["ms"], sharded["err"]
@@ -461,7 +461,7 @@ def main():
 
         th4 = threading.Thread(target=run_big, daemon=True)
         th4.start()
-        th4.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "180")))
+        th4.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "120")))
         if not big["done"]:
             big["err"] = "timeout: the configs[3] measurement did not complete"
 
