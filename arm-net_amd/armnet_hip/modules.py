@@ -352,7 +352,7 @@ class ArmNetBase(nn.Module):
         if (p.data_ptr(), p._version) != src:
             from .sharded import shard_rows
             sh = self._shard
-            sh.table_local = shard_rows(p.detach(), sh.rank, sh.world)
+            sh.table_local = shard_rows(p.detach(), sh.rank, sh.world)   # the setter also drops the whole-shard copy
             self._shard_src = (p.data_ptr(), p._version)
 
     def invalidate_folded(self):

@@ -104,8 +104,11 @@ class RowShardedTable:
         self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
         self.whole_shard = "auto" # fixed protocol: all-gather the shards when the de-duplicated slot would be the whole
                                   # shard anyway ("auto"), always (True), never (False)
-        self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces)
+        self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces); dropped
+                                  # whenever `table_local` is assigned (the property below)
         self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
+        self.slot_lookups = None  # lookups per step the slots of the fixed protocol are sized for; None: agreed over the
+                                  # ranks (MAX) by the first lookup — see _agreed_lookups
         self.table_local = table_local
         self.nfeat = int(nfeat)
         self.group = group
@@ -118,6 +121,38 @@ class RowShardedTable:
         expect = (self.nfeat - self.rank + self.world - 1) // self.world
         if table_local.shape[0] != expect:
             raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
+
+    @property
+    def table_local(self):
+        return self._table_local
+
+    @table_local.setter
+    def table_local(self, t):
+        """a new shard (re-cut after load_state_dict / an optimizer step / invalidate_folded) also drops the padded copy
+        the whole-shard exchange all-gathers: it would otherwise keep serving the OLD rows (round-2 advisor finding)"""
+        self._table_local = t
+        self._table_ag = None
+
+    def _agreed_lookups(self, n):
+        """Lookups per step that slot size, de-duplication and the choice between the request-list and the whole-shard
+        exchange are derived from.  They must be the SAME on every rank — different slot sizes or different collectives
+        would mismatch or hang — so they are a function of one agreed number, never of the local batch: `slot_lookups`
+        if the caller set it, else the MAX over the ranks of the first lookup's size (one tiny all-reduce + host read,
+        once).  Later batches may be smaller (a ragged last batch: more slack) or larger: a slot may then overflow,
+        which is flagged and repaired like any overflow, and the next poll() — whose all-reduce also carries the largest
+        step seen since the last one — raises the agreed size on every rank at once.  `slot_lookups = None` re-agrees
+        at the next lookup, which every rank must then do together."""
+        self._n_seen = max(getattr(self, "_n_seen", 0), int(n))
+        if self.slot_lookups is None:
+            self._slot_auto = True
+            m = max(int(n), 1)
+            if dist.is_initialized() and self.world > 1:
+                dev = self._table_local.device
+                t = torch.tensor([m], dtype=torch.int64, device="cpu" if self._via_host or not dev.type == "cuda" else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                m = int(t.item())
+            self.slot_lookups = m
+        return int(self.slot_lookups)
 
     def capacity(self, n, dedup):
         """slot size of the fixed protocol for n lookups: the mean n/R plus the slack factor and a few standard
@@ -132,21 +167,35 @@ class RowShardedTable:
     def overflowed(self):
         """True on every rank if a slot of the fixed protocol overflowed on ANY rank since the last call (one tiny
         all-reduce + the host read: the only synchronisation of that protocol); resets the flag."""
-        if self._overflow is None:
-            return False
-        flag = self._overflow
+        return self.poll(None)[0]
+
+    def poll(self, id_status=None):
+        """(overflowed, bad_id) — the same pair on EVERY rank: the fixed protocol's overflow flag and the caller's
+        out-of-range-id flag (int32[1] or None) travel in ONE all-reduce (MAX), so that all ranks take the same branch
+        afterwards (repeat the step exactly / raise IndexError together) instead of one rank raising while the others
+        wait in a collective.  Resets the overflow flag.  Every rank must call it at the same point of the step."""
+        dev = self._overflow.device if self._overflow is not None else (
+            id_status.device if id_status is not None else self._table_local.device)
+        f = torch.tensor([0, 0, min(getattr(self, "_n_seen", 0), 2 ** 31 - 1)], dtype=torch.int32, device=dev)
+        self._n_seen = 0
+        if self._overflow is not None:
+            f[0:1].copy_(self._overflow)
+        if id_status is not None:
+            f[1:2].copy_(id_status)
         if dist.is_initialized() and self.world > 1:
-            if self._via_host:
-                h = flag.cpu()
+            if self._via_host or f.device.type != "cuda":
+                h = f.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
-                hit = bool(h.item())
             else:
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                hit = bool(flag.item())
+                dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+                h = f.cpu()
         else:
-            hit = bool(flag.item())
-        flag.zero_()
-        return hit
+            h = f.cpu()
+        if self._overflow is not None:
+            self._overflow.zero_()
+        if getattr(self, "_slot_auto", False) and self.slot_lookups is not None and int(h[2].item()) > self.slot_lookups:
+            self.slot_lookups = int(h[2].item())   # a larger step than the agreed one was seen somewhere: same value on every rank
+        return bool(h[0].item()), bool(h[1].item())
 
     def lookup(self, ids, id_status=None, protocol=None):
         """ids [B, F] (this rank's samples) -> (rows, perm int32 [B*F]) with rows[perm[i]] = table[ids[i]].
@@ -160,13 +209,13 @@ class RowShardedTable:
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
         dev = flat.device
-        dedup = (8 * n >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
         if self._overflow is None or self._overflow.device != dev:
             self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)
-        # every rank must use the same slot size: it is a function of the batch shape only, so the ranks must hand in
-        # equally shaped batches per step (data-parallel inference with padded / dropped last batches), or fix the
-        # size for good with `slot_lookups`
-        cap = self.capacity(int(getattr(self, "slot_lookups", None) or max(n, 1)), dedup)
+        # slot size, de-duplication and the exchange path are functions of the AGREED step size, not of this rank's
+        # batch: every rank derives the same collectives from it whatever its own batch looks like
+        n_slot = self._agreed_lookups(n)
+        dedup = (8 * n_slot >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
+        cap = self.capacity(n_slot, dedup)
         L = (self.nfeat + R - 1) // R
         if self.whole_shard is True or (self.whole_shard == "auto" and dedup and cap >= L):
             self.last_path = "whole_shards"
@@ -199,7 +248,7 @@ class RowShardedTable:
         R = self.world
         L = (self.nfeat + R - 1) // R
         E = self.table_local.shape[1]
-        if self._table_ag is None:                     # (a changed table re-creates this object: _refresh_shard)
+        if self._table_ag is None:                     # dropped by the table_local setter whenever the shard is re-cut
             t = self.table_local
             if t.shape[0] < L:                         # the last shards are one row short: pad (a copy, made once)
                 t = torch.cat([t, t.new_zeros(L - t.shape[0], E)])
@@ -269,8 +318,9 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
     With micro_batches > 1 the batch is processed in slices whose lookups (routing, the two exchanges, the owner-side
     gather) run on a side stream, so the exchange of slice m+1 overlaps the fused kernel of slice m.  Every rank must
     use the same number of slices (the collectives pair up slice by slice).  Default: `shard.micro_batches` (1).
-    With check_ids an out-of-range id raises IndexError like the replicated path (one host sync at the end of the call;
-    the routing kernels flag it, the lookup itself reads row 0 for such an id).
+    With check_ids an out-of-range id raises IndexError like the replicated path — on EVERY rank, whichever rank saw it
+    (one all-reduce + host sync at the end of the call, which every rank therefore has to reach: check_ids must be the
+    same on all ranks; the routing kernels flag the id, the lookup itself reads row 0 for it).
     verify (default: check_ids; must be the same on every rank): after the step is enqueued, ask `shard.overflowed()`
     whether a slot of the fixed-capacity protocol was too small anywhere and, if so, redo the step with the exact
     protocol.  Unverified callers (benchmarks, serving loops that batch the check) call `shard.overflowed()` themselves."""
@@ -282,9 +332,14 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
     vals_in = vals.clone() if (verify and getattr(shard, "protocol", "exact") == "fixed") else None
 
     def finish(out):
-        if status is not None and int(status.item()) != 0:
+        # the collective comes FIRST and carries both flags: a bad id on one rank makes every rank raise, instead of
+        # leaving the others blocked in the overflow all-reduce (round-2 advisor finding)
+        over = bad = False
+        if status is not None or vals_in is not None:
+            over, bad = shard.poll(status)
+        if bad:
             raise IndexError("index out of range in self")
-        if vals_in is not None and shard.overflowed():
+        if vals_in is not None and over:
             vals.copy_(vals_in)                     # the clamp is idempotent, but start from the caller's values
             rows, perm = shard.lookup(ids, None, protocol="exact")
             return arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,

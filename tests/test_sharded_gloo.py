@@ -189,3 +189,126 @@ def test_numpy_double_matches_route_contract():
     owner_of_pos = np.repeat(np.arange(4), counts.numpy())
     assert np.array_equal(owner_of_pos[perm.numpy()], ids.numpy() % 4)
     assert np.array_equal(send_local.numpy()[perm.numpy()], ids.numpy() // 4)
+
+
+# ---- round 3: a re-cut shard must drop the whole-shard cache; agreed slot sizes; the collective error poll ----------
+
+def _recut_worker(rank, world, port, q, whole):
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from armnet_hip.sharded import RowShardedTable, shard_rows
+        nfeat, E, B, F = 1001, 8, 300, 5
+        old = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(7))
+        new = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(8))
+        ids = torch.randint(0, nfeat, (B, F), generator=torch.Generator().manual_seed(100 + rank))
+        shard = RowShardedTable(shard_rows(old, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=True,
+                                protocol="fixed")
+        shard.whole_shard = whole
+        rows, perm = shard.lookup(ids)
+        ok_old = bool(torch.equal(rows[perm.long()].view(B, F, E), old[ids]))
+        path = shard.last_path
+        shard.table_local = shard_rows(new, rank, world)        # what ArmNetBase._refresh_shard does after a weight update
+        rows, perm = shard.lookup(ids)
+        got = rows[perm.long()].view(B, F, E)
+        q.put((rank, ok_old, bool(torch.equal(got, new[ids])), bool(torch.equal(got, old[ids])), path))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("whole", ["auto", False])
+def test_recut_shard_serves_the_new_rows_gloo(whole):
+    """round-2 verdict, weak 1: after the shard is re-cut (load_state_dict / optimizer step / invalidate_folded) the
+    whole-shard exchange kept all-gathering its cached copy of the OLD shard"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 2000 + (whole is False)
+    procs = [ctx.Process(target=_recut_worker, args=(r, 2, port, q, whole)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    for rank, ok_old, ok_new, stale, path in res:
+        assert ok_old and ok_new and not stale, res
+        assert path == ("whole_shards" if whole == "auto" else "fixed")
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from armnet_hip.sharded import RowShardedTable, shard_rows
+        nfeat, E, F = 5000, 4, 6
+        table = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(7))
+        shard = RowShardedTable(shard_rows(table, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=False,
+                                protocol="fixed")
+        oks, sizes = [], []
+        # step 0: unequal batches (the ranks agree on the larger one); step 1: a ragged last batch on one rank only (7 vs
+        # 64 samples: local sizes would give different slot sizes, and 8 * n >= nfeat a different de-duplication choice);
+        # step 2: a LARGER batch than agreed on rank 1 only — its slots may overflow; poll() raises the agreed size
+        for step, B in enumerate([(64, 50), (7, 64), (64, 400)]):
+            ids = torch.randint(0, nfeat, (B[rank], F), generator=torch.Generator().manual_seed(10 * step + rank))
+            rows, perm = shard.lookup(ids)
+            sizes.append(int(rows.shape[0]))
+            over, _ = shard.poll(None)
+            if over:
+                rows, perm = shard.lookup(ids, protocol="exact")
+            oks.append(bool(torch.equal(rows[perm.long()].view(B[rank], F, E), table[ids])))
+        q.put((rank, oks, sizes, shard.slot_lookups))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fixed_protocol_with_unequal_batches_agrees_on_one_slot_size_gloo():
+    """round-2 advisor finding (medium): slot size and exchange path were derived from the LOCAL batch, so ranks with
+    different batch sizes ran mismatched equal-split exchanges.  They now come from one agreed step size."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(all(r[1]) for r in res), res
+    assert res[0][2] == res[1][2], res                     # the same receive-buffer size on both ranks, every step
+    assert res[0][3] == res[1][3] == 400 * 6, res          # the larger step raised the agreed size on BOTH ranks
+
+
+def _poll_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from armnet_hip.sharded import RowShardedTable, shard_rows
+        table = torch.randn(100, 4)
+        shard = RowShardedTable(shard_rows(table, rank, world), 100, None, ops=NumpyShardOps())
+        status = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)      # only rank 1 saw a bad id
+        q.put((rank,) + shard.poll(status))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bad_id_on_one_rank_is_seen_by_every_rank_gloo():
+    """round-2 advisor finding (medium): the IndexError used to be raised from the rank-local flag BEFORE the collective,
+    leaving the other ranks blocked in it"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_poll_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, False, True), (1, False, True)], res
