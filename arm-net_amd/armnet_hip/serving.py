@@ -28,19 +28,42 @@ class InFlight:
         self._k += 1
         return s
 
+    def _warm(self):
+        """refresh the lazily built parameter caches (q_fold + BatchNorm affine, the MLPs' packed / folded weights) on the
+        CALLER's stream: they are produced by whichever stream first needs them and then read by every later submit on
+        other streams, so they must exist before the side streams fork off (advisor finding r2)"""
+        m = self.model
+        with torch.no_grad():
+            if hasattr(m, "_folded") and hasattr(m, "attn_layer") and hasattr(m, "_d_k"):
+                at = m.attn_layer
+                bw = at.bilinear_w.weight if hasattr(at.bilinear_w, "weight") else at.bilinear_w
+                m._folded.get(m.variant, m.nhead, m.nhid, m.nemb, m._d_k(), bw, at.query, m.arm_bn)
+            if self.call != "arm_block" and not m.training:
+                for sub in m.modules():
+                    if hasattr(sub, "_hip_plan") and hasattr(sub, "_pack"):
+                        if sub.hip_head and sub._hip_plan() is not None:
+                            sub._pack()
+                        elif sub.fold_eval:
+                            sub._fold()
+
     def submit(self, ids, vals):
-        """Enqueue one batch; returns a handle for result().  x['value'] semantics: vals is clamped in place."""
+        """Enqueue one batch; returns a handle for result().  x['value'] semantics: vals is clamped in place.
+        The handle keeps ids / vals alive, and both are recorded on the side stream, so a caller that passes temporaries
+        (`fl.submit(i, v.clone())`) cannot have their memory handed out again while the side stream still reads them."""
+        self._warm()
         s = self._stream(vals.device)
         s.wait_stream(torch.cuda.current_stream(vals.device))        # the inputs were produced on the caller's stream
+        ids.record_stream(s)
+        vals.record_stream(s)
         with torch.no_grad(), torch.cuda.stream(s):
             y = self.model.arm_block(ids, vals) if self.call == "arm_block" else self.model({"id": ids, "value": vals})
             done = s.record_event()
-        return y, done, s
+        return y, done, s, (ids, vals)
 
     @staticmethod
     def result(handle):
         """Make the caller's current stream wait for that batch and hand out its tensor."""
-        y, done, _ = handle
+        y, done = handle[0], handle[1]
         cur = torch.cuda.current_stream(y.device)
         cur.wait_event(done)
         y.record_stream(cur)

@@ -146,9 +146,7 @@ static int launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     const size_t bytes = need(S) * sizeof(float);
     if (bytes > 150 * 1024) return ARMNET_ERR_UNSUPPORTED;
     auto kern = fused_bwd_kernel<IdT, TPB>;
-    if (bytes > 64 * 1024)
-        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ARMNET_ALLOW_BIG_LDS(kern, bytes);
     int64_t grid = (a.B + S - 1) / S;
     if (grid > 1024) grid = 1024;
     kern<<<(int)grid, TPB, bytes, st>>>(a, S);

@@ -707,9 +707,7 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
     auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC>;
-    if (lds > 64 * 1024)
-        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ARMNET_ALLOW_BIG_LDS(kern, lds);
     kern<<<(int)want, 256, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;

@@ -859,9 +859,7 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     }
 #endif
     auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL>;
-    if (lds > 64 * 1024)
-        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ARMNET_ALLOW_BIG_LDS(kern, lds);
     kern<<<(int)want, 64 * wpb, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;

@@ -551,9 +551,7 @@ static int launch_mlp_kw(const MlpArgs& a, hipStream_t st) {
     const size_t lds = (size_t)kWRing * NT * 3 * 1024 + ((((size_t)3 * NT * 32 + 4) * sizeof(float) + 15) & ~(size_t)15) +
                        (size_t)kWaves * kXRing * 2048;
     auto kern = mlp_head_kernel<NT, kWaves>;
-    if (lds > 64 * 1024)
-        ARMNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ARMNET_ALLOW_BIG_LDS(kern, lds);
     const int64_t blocks = (a.B + 32 * kWaves - 1) / (32 * kWaves);
     kern<<<(int)blocks, 64 * kWaves, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();

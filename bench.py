@@ -248,6 +248,18 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU over RCCL), exactly the
+        # command the driver would use; rank 0 of the child job prints the JSON line on the inherited stdout
+        import socket
+        import subprocess
+        os.dup2(json_fd, 1)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.shard is None:
         a.shard = "both" if world > 1 else "replicate"
@@ -341,9 +353,77 @@ def main():
     # Row-sharded variant: same model, same batches, the table row-sharded over the ranks and fetched by all-to-all.
     # It runs AFTER the headline numbers are final and under a watchdog: whatever happens in there (an exception on
     # one rank, a collective that never completes) must not cost the main line.
-    sharded = {"ms": float("nan"), "err": None, "done": False, "by_in_flight": {}, "in_flight": 1}
+    sharded = {"ms": float("nan"), "err": None, "done": False, "by_in_flight": {}, "in_flight": 1, "modes": {}}
     if a.shard == "both":
         import threading
+
+        def measure_mode(whole):
+            """one exchange of the row-sharded step (whole = "auto": whole-shard all-gather when the batch covers the
+            table | False: the request-list all-to-all protocol north_star names), with 1 and a.in_flight steps in flight"""
+            sh = model._shard
+            sh.whole_shard = whole
+            sh.slot_lookups = None                           # agreed again (all ranks arrive here together)
+            mode = {"by_in_flight": {}}
+            # `in_flight` steps on alternating streams (a serving loop with that many batches in flight): the row
+            # exchange of step i+1 overlaps the fused kernel of step i.  The collectives stay in issue order on the
+            # process group's own stream; the timed region ends with a device-wide synchronize.  Measured with one
+            # step in flight first, then with a.in_flight: the faster one is the mode's number, both are reported
+            # (and a failure of the second keeps the first).
+            n_settle = int(min(2000, max(0.0, a.settle_ms) / max(1e-3, 2.0 * res[head][0] / a.steps)))
+            if backend != "nccl":
+                n_settle = min(n_settle, 10)                 # host-staged developer path: a step takes tens of ms
+            for nfl in sorted({1, max(1, a.in_flight)}):
+                try:
+                    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+                    for s_ in streams:
+                        s_.wait_stream(torch.cuda.current_stream())
+                    turn = [0]
+
+                    def step_sharded():
+                        k = turn[0] % NB
+                        s_ = streams[turn[0] % nfl]
+                        turn[0] += 1
+                        with torch.no_grad(), torch.cuda.stream(s_):
+                            return model.arm_block(batches[k][0], batches[k][1])
+
+                    # clocks: every step holds collectives, so the untimed pre-run is a step COUNT that is the same
+                    # on every rank (from the all-reduced replicated step time), not a time budget
+                    for _ in range(n_settle):
+                        step_sharded()
+                    for _ in range(a.warmup):
+                        step_sharded()
+                    ms, _ = timed(step_sharded, a.steps, sync_all)
+                    ts = torch.tensor([ms], device=dev, dtype=torch.float64)
+                    if use_dist:
+                        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                    # the fixed-capacity protocol never looked at a count on the host: check its overflow flag ONCE,
+                    # after the timed steps (a set flag means some lookups read a wrong row: the number would be void)
+                    if bool(sh.overflowed()):
+                        mode["overflow"] = True
+                    mode["by_in_flight"][str(nfl)] = float(ts.item())
+                except Exception as e:  # noqa: BLE001
+                    if not mode["by_in_flight"]:
+                        raise
+                    mode["in_flight_err"] = f"in_flight={nfl}: {type(e).__name__}: {e}"
+            mode["exchange"] = getattr(sh, "last_path", None)
+            best = min(mode["by_in_flight"], key=mode["by_in_flight"].get)
+            mode["ms"], mode["in_flight"] = mode["by_in_flight"][best], int(best)
+            # bytes one rank RECEIVES from the other ranks per step, and what that means per xGMI link (R - 1 peers, one
+            # link each): a link-bound result is then legible in the line
+            R, E4 = world, a.nemb * 4
+            n_lk = a.batch * a.nfield
+            if mode["exchange"] == "whole_shards":
+                per_peer = ((a.nfeat + R - 1) // R) * E4
+            else:
+                n_slot = sh.slot_lookups or n_lk
+                dd = (8 * n_slot >= a.nfeat) if sh.dedup == "auto" else bool(sh.dedup)
+                cap = sh.capacity(n_slot, dd)
+                per_peer = cap * (E4 + 4)                    # the rows it asked for + the request list it answers
+                mode["slot_rows"] = cap
+            mode["ingress_bytes_per_rank_per_step"] = per_peer * (R - 1)
+            if R > 1:
+                mode["implied_gb_per_s_per_link"] = per_peer / (mode["ms"] / a.steps * 1e-3) / 1e9
+            return mode
 
         def run_sharded():
             try:
@@ -352,60 +432,26 @@ def main():
                 model._shard.micro_batches = a.micro_batches
                 model._shard.protocol = a.protocol
                 model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
-                model._shard.whole_shard = "auto" if a.whole_shard == "auto" else False
-                turn = [0]
-
-                # `in_flight` steps on alternating streams (a serving loop with that many batches in flight): the row
-                # exchange of step i+1 overlaps the fused kernel of step i.  The collectives stay in issue order on the
-                # process group's own stream; the timed region ends with a device-wide synchronize.  Measured with one
-                # step in flight first, then with a.in_flight: the faster one is the row-sharded number, both are reported
-                # (and a failure of the second mode keeps the first).
-                n_settle = int(min(2000, max(0.0, a.settle_ms) / max(1e-3, 2.0 * res[head][0] / a.steps)))
-                if backend != "nccl":
-                    n_settle = min(n_settle, 10)             # host-staged developer path: a step takes tens of ms
-                for nfl in sorted({1, max(1, a.in_flight)}):
-                    try:
-                        streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-                        for s_ in streams:
-                            s_.wait_stream(torch.cuda.current_stream())
-                        turn = [0]
-
-                        def step_sharded():
-                            k = turn[0] % NB
-                            s_ = streams[turn[0] % nfl]
-                            turn[0] += 1
-                            with torch.no_grad(), torch.cuda.stream(s_):
-                                return model.arm_block(batches[k][0], batches[k][1])
-
-                        # clocks: every step holds collectives, so the untimed pre-run is a step COUNT that is the same
-                        # on every rank (from the all-reduced replicated step time), not a time budget
-                        for _ in range(n_settle):
-                            step_sharded()
-                        for _ in range(a.warmup):
-                            step_sharded()
-                        ms, _ = timed(step_sharded, a.steps, sync_all)
-                        ts = torch.tensor([ms], device=dev, dtype=torch.float64)
-                        if use_dist:
-                            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-                        # the fixed-capacity protocol never looked at a count on the host: check its overflow flag ONCE,
-                        # after the timed steps (a set flag means some lookups read a wrong row: the number would be void)
-                        if bool(model._shard.overflowed()):
-                            sharded["overflow"] = True
-                        sharded["by_in_flight"][str(nfl)] = float(ts.item())
-                    except Exception as e:  # noqa: BLE001
-                        if not sharded["by_in_flight"]:
-                            raise
-                        sharded["in_flight_err"] = f"in_flight={nfl}: {type(e).__name__}: {e}"
-                sharded["exchange"] = getattr(model._shard, "last_path", None)
-                best = min(sharded["by_in_flight"], key=sharded["by_in_flight"].get)
-                sharded["ms"], sharded["in_flight"] = sharded["by_in_flight"][best], int(best)
+                plan = ["auto", False] if a.whole_shard == "auto" else [False]
+                for whole in plan:
+                    m_ = measure_mode(whole)
+                    if m_["exchange"] in sharded["modes"]:
+                        continue                             # "auto" resolved to the request lists anyway
+                    sharded["modes"][m_["exchange"]] = m_
+                ok = {k: v for k, v in sharded["modes"].items() if not v.get("overflow")}
+                if not ok:
+                    sharded["overflow"] = True
+                    ok = sharded["modes"]
+                best = min(ok, key=lambda k: ok[k]["ms"])
+                sharded.update(ms=ok[best]["ms"], in_flight=ok[best]["in_flight"], exchange=best,
+                               by_in_flight=ok[best]["by_in_flight"], in_flight_err=ok[best].get("in_flight_err"))
             except Exception as e:  # noqa: BLE001
                 sharded["err"] = f"{type(e).__name__}: {e}"
             sharded["done"] = True
 
         th = threading.Thread(target=run_sharded, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "120")))
+        th.join(timeout=float(os.environ.get("ARMNET_BENCH_SHARDED_TIMEOUT", "180")))
         if not sharded["done"]:
             sharded["err"] = "timeout: the row-sharded measurement did not complete (collective hang?)"
     sharded_ms, sharded_err = sharded["ms"], sharded["err"]
@@ -524,7 +570,8 @@ def main():
                                    f"(ids+vals+out = {ws_mb:.0f} MB per rotation > 256 MiB Infinity Cache; only "
                                    f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read); device clocks settled "
                                    f"by {a.settle_ms:g} ms of the same step, untimed, before the warm-up steps",
-                       "global_batch": world * a.batch, "parallelism": parallelism, "clock_settle_ms": a.settle_ms},
+                       "global_batch": world * a.batch, "parallelism": parallelism, "clock_settle_ms": a.settle_ms,
+                       "ids": a.ids},
             "roofline": roof(head),
             "regimes": {r: regime_obj(r) for r in regimes},
             "full_forward": {"value": world * a.batch * a.steps / (full_wall_ms * 1e-3), "unit": "samples/s",
@@ -555,22 +602,34 @@ def main():
             line["row_sharded"] = {"error": sharded_err,
                                    "note": "`value` falls back to the replicated-table number for this line"}
         elif a.shard == "both":
+            def mode_obj(m_):
+                o = {"value": world * a.batch * a.steps / (m_["ms"] * 1e-3), "unit": "samples/s",
+                     "ms_per_step": m_["ms"] / a.steps, "steps_in_flight": m_["in_flight"],
+                     "samples_per_s_by_steps_in_flight": {k: world * a.batch * a.steps / (v * 1e-3)
+                                                          for k, v in m_["by_in_flight"].items()},
+                     "ingress_bytes_per_rank_per_step": m_["ingress_bytes_per_rank_per_step"],
+                     "implied_gb_per_s_per_link": m_.get("implied_gb_per_s_per_link")}
+                for k in ("slot_rows", "overflow", "in_flight_err"):
+                    if m_.get(k) is not None:
+                        o[k] = m_[k]
+                return o
+
             line["row_sharded"] = {
                 "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
                 "ms_per_step": sharded_ms / a.steps, "steps_in_flight": sharded["in_flight"],
-                "samples_per_s_by_steps_in_flight": {k: world * a.batch * a.steps / (v * 1e-3)
-                                                     for k, v in sharded["by_in_flight"].items()},
-                "in_flight_error": sharded.get("in_flight_err"), "exchange": sharded.get("exchange"),
-                "note": f"(= `value`) the block with the table row-sharded (row i on rank i mod {world}), no host "
-                        f"synchronisation in the step.  exchange = whole_shards: this batch asks for (nearly) every row "
-                        f"of every shard ({a.batch * a.nfield} lookups of {a.nfeat} rows per rank), so the owners ship "
-                        f"their shards as they are — one all_gather_into_tensor of {a.nfeat * a.nemb * 4 / 1e6:.0f} MB "
-                        f"per rank and step into a transient buffer, direct row addresses — instead of answering "
-                        f"request lists.  exchange = fixed (sparser batches, --whole-shard off): HIP routing with per-rank id de-duplication (direct-address mark + "
-                        f"scan), fixed-capacity slots, equal-split all_to_all_single of int32 row indices, owner-side "
-                        f"gather, equal-split all_to_all_single of {a.nemb * 4}-byte rows (one per DISTINCT id: at most "
-                        f"{a.batch * a.nfield * a.nemb * 4 / 1e6:.0f} MB per rank per step, {(world - 1) / world:.0%} of it "
-                        f"across xGMI), fused kernel over (rows, perm); overflow flag checked after the timed steps; "
+                "exchange": sharded.get("exchange"), "ids": a.ids,
+                "by_exchange": {k: mode_obj(v) for k, v in sharded["modes"].items()},
+                "note": f"(= `value`: the faster exchange, named in `exchange`) the block with the table row-sharded (row i "
+                        f"on rank i mod {world}), no host synchronisation in the step; ids {a.ids}.  by_exchange.fixed = the "
+                        f"request-list protocol north_star names: HIP routing with per-rank id de-duplication "
+                        f"(direct-address mark + scan), fixed-capacity slots, equal-split all_to_all_single of int32 row "
+                        f"indices, owner-side gather, equal-split all_to_all_single of {a.nemb * 4}-byte rows (one per "
+                        f"DISTINCT id), fused kernel over (rows, perm); overflow flag checked after the timed steps.  "
+                        f"by_exchange.whole_shards (only when the batch covers the table: {a.batch * a.nfield} lookups of "
+                        f"{a.nfeat} rows per rank): the owners ship their shards as they are — one all_gather_into_tensor "
+                        f"of {a.nfeat * a.nemb * 4 / 1e6:.0f} MB per rank and step into a transient buffer, direct row "
+                        f"addresses — instead of answering request lists.  ingress_bytes_per_rank_per_step = what one rank "
+                        f"receives from its {world - 1} peers; implied_gb_per_s_per_link = that per peer / step time.  "
                         f"steps_in_flight > 1: consecutive steps alternate between that many streams, so the row exchange "
                         f"of one step runs under the fused kernel of the previous one"}
         if big["done"] or big["err"]:

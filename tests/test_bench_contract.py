@@ -58,6 +58,23 @@ def test_single_gpu_line_has_the_contract_keys_and_both_objects():
     assert fl["n"] == 2 and fl["value"] > 0 and fl["full_forward_samples_per_s"] > 0
 
 
+def _check_two_rank_line(d):
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    rs, rep = d["row_sharded"], d["replicated"]
+    assert "error" not in rs, rs
+    assert d["value"] == rs["value"] and rep["value"] > 0
+    # three numbers, always: replicated, the request-list all-to-all protocol ("fixed") and the whole-shard exchange
+    by = rs["by_exchange"]
+    assert set(by) == {"whole_shards", "fixed"} and rs["exchange"] in by and rs["ids"] == "uniform"
+    assert rs["value"] == max(v["value"] for v in by.values())
+    for v in by.values():
+        assert set(v["samples_per_s_by_steps_in_flight"]) == {"1", "2"}
+        assert v["ingress_bytes_per_rank_per_step"] > 0 and v["implied_gb_per_s_per_link"] > 0
+    assert by["whole_shards"]["ingress_bytes_per_rank_per_step"] == 500_000 * 64     # the other rank's shard
+    assert "row-sharded" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
+
+
 @pytest.mark.gpu
 def test_two_rank_line_reports_the_row_sharded_step_as_value():
     env = dict(os.environ, ARMNET_BENCH_BACKEND="gloo", ARMNET_BENCH_DEVICE="0")
@@ -66,11 +83,17 @@ def test_two_rank_line_reports_the_row_sharded_step_as_value():
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--regime", "fresh", "--no-config4"],
                        cwd=ROOT, env=env, capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    d = _one_json_line(p.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
-    rs, rep = d["row_sharded"], d["replicated"]
-    assert "error" not in rs, rs
-    assert d["value"] == rs["value"] and rep["value"] > 0
-    assert rs["exchange"] == "whole_shards" and set(rs["samples_per_s_by_steps_in_flight"]) == {"1", "2"}
-    assert "row-sharded" in d["config"]["parallelism"]
-    assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
+    _check_two_rank_line(_one_json_line(p.stdout))
+
+
+@pytest.mark.gpu
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
+    """round-2 verdict, missing 2: `python bench.py --gpus N` without torch.distributed.run used to die on an assert;
+    it now launches the N ranks itself and rank 0 prints the one line"""
+    env = dict(os.environ, ARMNET_BENCH_BACKEND="gloo", ARMNET_BENCH_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--regime", "fresh", "--no-config4"], cwd=ROOT, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _check_two_rank_line(_one_json_line(p.stdout))
