@@ -499,8 +499,9 @@ class _MLP(nn.Module):
     (armnet_mlp_head_f32, csrc/mlp_head.hip: BatchNorm folded into the weights, W' = W * s, b' = b * s + t with
     s = gamma / sqrt(var + eps), t = beta - mean * s; operands split into three bf16 slices, six cross products on the
     bf16 matrix cores, fp32 accumulate; packed weights refreshed when any source tensor's version counter moves) for
-    heads with 1..n hidden layers of width <= 256 and one output — every head the reference builds.  Anything else
-    (no hidden layer, several outputs, wider layers, `hip_head = False`) takes one hipBLASLt GEMM per folded
+    heads with 1..n hidden layers and one output — every head the reference builds; hidden widths above 256 (run.sh's
+    500) run as slices of <= 256 units through the same kernel (_hip_plan).  Anything else (no hidden layer, several
+    outputs, `hip_head = False`) takes one hipBLASLt GEMM per folded
     (Linear, BatchNorm1d, ReLU, Dropout) group with a bias+ReLU epilogue."""
 
     def __init__(self, ninput, nlayers, nhid, dropout, noutput=1):
@@ -528,17 +529,34 @@ class _MLP(nn.Module):
         self._pack_key = None
         self._packed = None
 
+    HIP_MAX_SLICE = 256            # hidden units per launch of the head kernel
+
     def _hip_plan(self):
-        """launch plan of the HIP head: [(first hidden layer index, number of hidden layers fused, has_final)], or
-        None when there is no kernel for this head (no hidden layer, more than one output, hidden width > 256)"""
+        """launch plan of the HIP head: [(first hidden layer, hidden layers fused, has_final, n0, n1)], or None when
+        there is no kernel for this head (no hidden layer, more than one output).  Hidden width <= 256: up to two hidden
+        layers (+ the final Linear) per launch.  Wider (run.sh:18-19,44-45 build mlp_hid / dnn_hid 500): one hidden
+        layer per launch, cut into slices [n0, n1) of <= 256 units that write their columns of a [B, nhid] buffer; in
+        the last hidden layer the first slice writes its share of the final Linear (has_final 1) and the others add
+        theirs (has_final 2)."""
         ninput, nlayers, nhid, noutput = self._dims
-        if nlayers < 1 or noutput != 1 or not native.mlp_head_supported(ninput, nhid, 1):
+        if nlayers < 1 or noutput != 1 or nhid < 1:
             return None
+        S = self.HIP_MAX_SLICE
         plan, i = [], 0
-        while i < nlayers:
-            n = 2 if nlayers - i >= 2 else 1
-            plan.append((i, n, i + n == nlayers))
-            i += n
+        if nhid <= S:
+            if not native.mlp_head_supported(ninput, nhid, 1):
+                return None
+            while i < nlayers:
+                n = 2 if nlayers - i >= 2 else 1
+                plan.append((i, n, 1 if i + n == nlayers else 0, 0, nhid))
+                i += n
+            return plan
+        nsl = (nhid + S - 1) // S
+        w = ((nhid + nsl - 1) // nsl + 31) // 32 * 32            # equal slices, whole 32-unit tiles
+        for i in range(nlayers):
+            for k, n0 in enumerate(range(0, nhid, w)):
+                last = i + 1 == nlayers
+                plan.append((i, 1, (1 if k == 0 else 2) if last else 0, n0, min(nhid, n0 + w)))
         return plan
 
     def _groups(self):
@@ -557,36 +575,47 @@ class _MLP(nn.Module):
             dev = last.weight.device
             packed = []
             with torch.no_grad():
-                for first, n, has_final in self._hip_plan():
+                for first, n, has_final, n0, n1 in self._hip_plan():
                     K0 = ninput if first == 0 else nhid
-                    blob = torch.zeros(native.mlp_packed_bytes(K0, nhid, n), device=dev, dtype=torch.uint8)
+                    wid = n1 - n0                                   # units of this launch (a slice of a wider layer)
+                    blob = torch.zeros(native.mlp_packed_bytes(K0, wid, n), device=dev, dtype=torch.uint8)
                     for slot in range(n):
                         lin, bn = hidden[first + slot]
-                        native.mlp_pack_layer(K0, nhid, n, slot, lin.weight.detach().contiguous(), lin.bias.detach(),
-                                              (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                        native.mlp_pack_layer(K0, wid, n, slot, lin.weight.detach()[n0:n1].contiguous(),
+                                              lin.bias.detach()[n0:n1].contiguous(),
+                                              (bn.weight.detach()[n0:n1].contiguous(), bn.bias.detach()[n0:n1].contiguous(),
+                                               bn.running_mean[n0:n1].contiguous(), bn.running_var[n0:n1].contiguous(),
                                                float(bn.eps)), blob)
-                    if has_final:
-                        native.mlp_pack_layer(K0, nhid, n, 2, last.weight.detach().contiguous(), last.bias.detach(),
-                                              None, blob)
-                    packed.append((K0, n, has_final, blob))
+                    if has_final:                                   # the bias rides with the first slice only
+                        native.mlp_pack_layer(K0, wid, n, 2, last.weight.detach()[:, n0:n1].contiguous(),
+                                              last.bias.detach() if has_final == 1 else None, None, blob)
+                    packed.append((first, K0, n, has_final, n0, n1, blob))
             self._packed, self._pack_key = packed, key
         return self._packed
 
     def _hip_forward(self, x):
         nhid = self._dims[2]
         B = x.shape[0]
-        for K0, n, has_final, blob in self._pack():
+        NP = (nhid + 15) // 16 * 16
+        cur, cur_layer = x, 0                          # activations feeding hidden layer `cur_layer`
+        nxt = logits = None
+        for first, K0, n, has_final, n0, n1, blob in self._pack():
+            if first != cur_layer:                     # the previous layer's slices are complete
+                cur, cur_layer, nxt = nxt, first, None
             KP = (K0 + 15) // 16 * 16
-            if x.shape[1] < KP and (x.stride(0) < KP or B == 1):
+            if cur.shape[1] < KP and (cur.stride(0) < KP or B == 1):
                 # the kernel reads whole 16-float k-steps: pad odd widths with zeros (heads whose input width is a
                 # multiple of 16 — every BASELINE.json configuration — take the activations as they are)
-                x = torch.nn.functional.pad(x, (0, KP - x.shape[1]))
-            NP = (nhid + 15) // 16 * 16
-            out = (torch.empty(B, device=x.device, dtype=torch.float32) if has_final
-                   else torch.zeros(B, NP, device=x.device, dtype=torch.float32))   # pad columns stay zero
-            native.mlp_head(B, K0, nhid, n, has_final, x, blob, out)
-            x = out
-        return x.view(B, 1)
+                cur = torch.nn.functional.pad(cur, (0, KP - cur.shape[1]))
+            if has_final:
+                if logits is None:
+                    logits = torch.empty(B, device=x.device, dtype=torch.float32)
+                native.mlp_head(B, K0, n1 - n0, n, has_final, cur, blob, logits)
+            else:
+                if nxt is None:
+                    nxt = torch.zeros(B, NP, device=x.device, dtype=torch.float32)   # pad columns stay zero
+                native.mlp_head(B, K0, n1 - n0, n, 0, cur, blob, nxt[:, n0:])
+        return logits.view(B, 1)
 
     def _fold(self):
         mods = list(self.mlp)

@@ -360,7 +360,8 @@ def mlp_pack_layer(K0, nhid, n_hidden, slot, W, b, bn, packed):
 
 def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
     """x: [B, >= K0] float32 with unit inner stride whose row stride covers 16 * ceil(K0 / 16) floats (columns past K0
-    readable and finite); out: [B] logits (has_final) or [B, >= nhid] hidden activations"""
+    readable and finite); out: [B] logits (has_final: 1 = write, 2 = add this slice's share) or [B, >= nhid] hidden
+    activations (a column slice of a wider buffer qualifies)"""
     if not (out.is_cuda and out.dtype == torch.float32 and (out.dim() == 1 or out.stride(1) == 1)):
         raise ArmnetNativeError("out: expected a float32 tensor with unit inner stride on the HIP device")
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
@@ -368,7 +369,7 @@ def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
     ldx = x.stride(0) if B > 1 else max(x.stride(0), x.shape[1])
     ldo = 0 if has_final else (out.stride(0) if B > 1 else max(out.stride(0), out.shape[1]))
     with _on(x, packed, out):
-        check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(bool(has_final)),
+        check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(has_final),
                                          _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
                                          _stream()))
 

@@ -60,10 +60,30 @@ __device__ __forceinline__ f32x2 pk_sub_clamp01(f32x2 x, f32x2 tau) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "v"(tau));
     return r;
 }
+// the same with ONE threshold for both elements: op_sel_hi makes the high half read the low dword of `tau`, so the
+// threshold needs no broadcast move (only tau[0] is read)
+__device__ __forceinline__ f32x2 pk_sub_clamp01_lo(f32x2 x, f32x2 tau) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "v"(tau));
+    return r;
+}
 // clamp01(a * b), two elements per instruction (indicator of a > 0 when b is huge)
 __device__ __forceinline__ f32x2 pk_mul_clamp01(f32x2 a, f32x2 b) {
     f32x2 r;
     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// the same with the second operand in scalar registers (a constant pair that never costs a VALU move)
+__device__ __forceinline__ f32x2 pk_mul_clamp01_s(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+// a + b that the SLP vectoriser cannot pair up with a neighbour
+__device__ __forceinline__ float vadd(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -574,28 +594,42 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                         f_lo[s] = Ssum[s] - 1.0f;
                         dm[s] = tau_hi[s] - tau[s];
                     }
+                    // a sample whose rows have all settled (tau_lo + dm == tau_lo: every later step would evaluate the same
+                    // tau_m again) leaves the loop on its own; its p and S are those of its last evaluation
+#ifdef ARMNET_SAMPLE_EXIT
+                    constexpr bool kBisectSampleExit = true;
+#else
+                    constexpr bool kBisectSampleExit = false;
+#endif
+                    unsigned long long live[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) live[s] = ~0ull;
                     for (int it = 0; it < a.cfg.n_iter; ++it) {
                         float tm[SPW];
-                        bool moving = false;
                         wave_lds_fence();
 #pragma unroll
                         for (int s = 0; s < SPW; ++s) {
+                            if (kBisectSampleExit && SPW > 1 && !live[s]) continue;                  // scalar branch
                             dm[s] *= 0.5f;
                             tm[s] = tau[s] + dm[s];
-                            moving |= !(tm[s] == tau[s]);                       // NaN rows never settle: all n_iter steps
                             red_write(red, s & 1, lane, eval(s, tm[s]), 0.f);
                         }
                         wave_lds_fence();
+                        unsigned long long any_live = 0;
 #pragma unroll
                         for (int s = 0; s < SPW; ++s) {
+                            if (kBisectSampleExit && SPW > 1 && !live[s]) continue;
                             const Red2 r = red_read(red, s & 1, c);
                             Ssum[s] = (r.g0[0] + r.g1[0]) + (r.g2[0] + r.g3[0]);
                             const float f_m = Ssum[s] - 1.0f;
+                            // NaN rows never settle: all n_iter steps
+                            live[s] = __builtin_amdgcn_ballot_w64(!(tm[s] == tau[s]));
                             tau[s] = (f_m * f_lo[s] >= 0.f) ? tm[s] : tau[s];
+                            any_live |= live[s];
                         }
                         // once tau_lo + dm rounds to tau_lo in every row of the wave (dm below half an ulp: ~25 steps),
                         // every later step would evaluate the same tau_m again: stopping here is bit-identical
-                        if (!__builtin_amdgcn_ballot_w64(moving)) break;
+                        if (!any_live) break;
                     }
                     PHASE(3);
 #pragma unroll
@@ -611,19 +645,35 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     // are kept as well, which saves their recomputation in the weight pass
                     constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && WPS <= 3);
                     f32x2 pkeep[KEEP ? SPW * NP : 1];
+                    // A sample whose 16 rows have all converged leaves the loop on its own (wave-uniform masks on the scalar
+                    // unit): with sparse supports the two samples of a group rarely finish in the same step.  Its tau, S and
+                    // kept clamped differences are those of ITS last evaluation, which was at its final thresholds.
+#ifdef ARMNET_SAMPLE_EXIT
+                    constexpr bool kSampleExit = true;
+#else
+                    constexpr bool kSampleExit = false;
+#endif
+                    unsigned long long live[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) live[s] = ~0ull;
+                    const f32x2 huge2 = {0x1p120f, 0x1p120f};
+                    f32x2 tau2[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) tau2[s] = f32x2{tau[s], tau[s]};
                     for (int it = 0; it < kNewtonMaxIter; ++it) {
                         wave_lds_fence();
 #pragma unroll
                         for (int s = 0; s < SPW; ++s) {
-                            const f32x2 tk = {tau[s], tau[s]};
+                            if (kSampleExit && SPW > 1 && !live[s]) continue;          // scalar branch
+                            tau2[s][0] = tau[s];                        // only the low half is read (op_sel_hi)
                             f32x2 S2, D2;
 #pragma unroll
                             for (int jp = 0; jp < NP; ++jp) {
-                                const f32x2 t = pk_sub_clamp01(XP_GET(s, jp), tk);
+                                const f32x2 t = pk_sub_clamp01_lo(XP_GET(s, jp), tau2[s]);
                                 f32x2 sv, dv;
                                 if constexpr (MODE == SOLVE_MICHELOT) {
                                     sv = t;
-                                    dv = pk_mul_clamp01(t, f32x2{0x1p120f, 0x1p120f});
+                                    dv = pk_mul_clamp01_s(t, huge2);
                                     if constexpr (KEEP) pkeep[s * NP + jp] = t;
                                 } else if constexpr (MODE == SOLVE_NEWTON15) {
                                     sv = t * t;
@@ -640,12 +690,18 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                                 S2 = jp == 0 ? sv : S2 + sv;
                                 D2 = jp == 0 ? dv : D2 + dv;
                             }
-                            red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
+                            // horizontal adds as plain v_add_f32: written as C++ the vectoriser packs {S2.x + S2.y, D2.x + D2.y}
+                            // into one v_pk_add_f32 behind six register shuffles
+                            // (NP == 1: the operands would be raw v_exp_f32 results, and inline asm is invisible to the
+                            // compiler's trans-use hazard handling: seen as NaNs / run-to-run differences at nfield <= 8)
+                            if constexpr (NP > 1) red_write(red, s & 1, lane, vadd(S2[0], S2[1]), vadd(D2[0], D2[1]));
+                            else red_write(red, s & 1, lane, S2[0] + S2[1], D2[0] + D2[1]);
                         }
                         wave_lds_fence();
-                        bool any_active = false;
+                        unsigned long long any_live = 0;
 #pragma unroll
                         for (int s = 0; s < SPW; ++s) {
+                            if (kSampleExit && SPW > 1 && !live[s]) continue;
                             const Red2 r = red_read(red, s & 1, c);
                             const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);     // {S, Dv} in one register pair
                             float Dv = sd[1];
@@ -654,11 +710,14 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                             Ssum[s] = sd[0];
                             const float f = sd[0] - 1.0f;
                             const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
-                            const bool act = (f > kNewtonTol) && (tn > tau[s]) && !dbg_no_solve;
+                            const bool c_f = f > kNewtonTol, c_t = tn > tau[s];
+                            const bool act = c_f && c_t && !dbg_no_solve;
                             tau[s] = act ? tn : tau[s];
-                            any_active |= act;
+                            // two compare masks and a scalar AND (the ballot of the combined bool costs two more VALU ops)
+                            live[s] = dbg_no_solve ? 0ull : (__builtin_amdgcn_ballot_w64(c_f) & __builtin_amdgcn_ballot_w64(c_t));
+                            any_live |= live[s];
                         }
-                        if (!__builtin_amdgcn_ballot_w64(any_active)) break;
+                        if (!any_live) break;
                     }
                     PHASE(3);
                     // unnormalised weights p * values (armnet_1h.py:34)

@@ -541,7 +541,11 @@ __global__ void __launch_bounds__(64 * kWaves, kWaves >= 8 ? 2 : 1) mlp_head_ker
     }
     if (a.has_final) {
         part += __shfl_xor(part, 32);
-        if (hf == 0 && row < a.B) a.out[row] = part + tabs[3 * NT * 32];
+        // has_final == 2: this launch holds a SLICE of a wider last hidden layer: add its share of the final Linear
+        if (hf == 0 && row < a.B) {
+            const float v = part + tabs[3 * NT * 32];
+            a.out[row] = a.has_final == 2 ? a.out[row] + v : v;
+        }
     }
 }
 
@@ -616,7 +620,8 @@ int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final
     if (B == 0) return ARMNET_OK;
     if (!x || !packed || !out) return ARMNET_ERR_BAD_ARG;
     MlpArgs a{};
-    a.B = B; a.K0 = K0; a.n_hidden = n_hidden; a.has_final = has_final ? 1 : 0; a.N = nhid; a.ldx = ldx; a.ldo = ldo;
+    if (has_final < 0 || has_final > 2) return ARMNET_ERR_BAD_ARG;
+    a.B = B; a.K0 = K0; a.n_hidden = n_hidden; a.has_final = has_final; a.N = nhid; a.ldx = ldx; a.ldo = ldo;
     a.x = x; a.packed = static_cast<const uint8_t*>(packed); a.out = out;
 #ifdef ARMNET_DEV_FLAGS
     if (const char* e = getenv("ARMNET_MLP_DBG")) a.dbg = atoi(e);

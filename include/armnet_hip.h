@@ -300,6 +300,11 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
  *   armnet_mlp_head_f32         x [B, K0] (row stride ldx floats) -> has_final ? out [B] (the logits, layers.py:88)
  *                                                                              : out [B, nhid] (post-ReLU activations,
  *                                                                                row stride ldo floats)
+ *       has_final = 2: out [B] += this launch's share of the final Linear (no overwrite).  Hidden layers wider than
+ *       256 (run.sh:18-19,44-45 ask for 500) run as SLICES of <= 256 units, one hidden layer per launch: a slice is a
+ *       layer of its own whose W / b / BatchNorm rows are the slice's (pointer offsets), whose activations land in
+ *       columns n0.. of a [B, ldo] buffer (out + n0), and whose share of the final Linear is written by the first
+ *       slice (has_final = 1, with the bias) and added by the others (has_final = 2, packed with b = NULL).
  *       x is read in whole 16-float k-steps: ldx >= 16 * ceil(K0 / 16), and the columns K0 .. of every row must be
  *       readable and finite (they meet zero weights).  A contiguous [B, K0] tensor qualifies when K0 % 16 == 0.
  */

@@ -316,6 +316,7 @@ def main():
     wide_cases()
     big_batch_grad_cases()
     sibling_cases()
+    wide_head_cases()
 
 
 def run_sh_cases():
@@ -396,6 +397,16 @@ def wide_cases():
     model_case("g11_criteo_mh4_a2.0_wide", "mh", base(39, 4096, 16, 2.0, 32, nhead=4), 64, 132, "wide4", keep=LEAN_MH)
     model_case("g11_criteo_1h_e64_a1.7_wide", "1h", base(39, 1024, 64, 1.7, 32), 64, 133, "wide", keep=LEAN_MH)
     model_case("g11_criteo_1h_h128_e10_a2.0_wide", "1h", base(39, 1024, 10, 2.0, 128, mlp_nhid=16), 64, 134, "wide", keep=LEAN_MH)
+
+
+def wide_head_cases():
+    """G12 (round 3) - heads wider than 256: run.sh:18-19,44-45 build the Criteo models with --mlp_hid 500 (and
+    --dnn_hid 500 for the ensemble's DNN); small blocks keep the fixtures at the size of the 500 x 500 layer"""
+    model_case("g12_criteo_1h_h16_e10_a2.0_mlp500", "1h", base(39, 400, 10, 2.0, 16, mlp_nhid=500), 9, 141, "stress",
+               keep=LEAN_MH)
+    model_case("g12_criteo_mh4_h8_e10_a2.0_ens_mlp500_dnn500", "mh",
+               base(10, 400, 10, 2.0, 8, nhead=4, ensemble=True, mlp_nhid=500, deep_nhid=500), 9, 142, "stress",
+               keep=LEAN_MH)
 
 
 def big_batch_grad_cases():
@@ -505,6 +516,8 @@ if __name__ == "__main__":
         b64_cases()
         wide_cases()
         big_batch_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round3-only":      # add the round-3 cases without rewriting the others
+        wide_head_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
         entmax_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":

@@ -37,13 +37,16 @@ def _ref64(m, x):
 # (nfield * nemb inputs), every tile count (hidden widths padded to 32/64/128/256), widths that are not multiples of 32
 # or 4, an input width with a partial last k-step, one / three / four hidden layers (chained launches)
 HEADS = [(512, 2, 256), (2048, 2, 256), (704, 2, 256), (320, 2, 32), (130, 1, 16), (100, 3, 64), (37, 1, 10),
-         (512, 2, 128), (17, 4, 8), (640, 2, 200), (1280, 1, 256), (390, 3, 16)]
+         (512, 2, 128), (17, 4, 8), (640, 2, 200), (1280, 1, 256), (390, 3, 16),
+         # wider than 256 (round 3; run.sh:18-19,44-45 build --mlp_hid 500 / --dnn_hid 500): slices of <= 256 units, one
+         # hidden layer per launch, the final Linear accumulated over the slices of the last hidden layer
+         (1280, 2, 500), (390, 2, 500), (512, 1, 300), (64, 3, 600), (100, 2, 257), (2048, 2, 512)]
 
 
 # the kernel runs with 4-wave blocks (128 samples) while all of them fit the chip at once (B <= 32 768) and with 8-wave
 # blocks (256 samples) beyond: both sides of the switch, ragged last blocks
 BIG = [(512, 2, 256, 33001), (512, 2, 256, 32768), (320, 2, 32, 40007), (130, 1, 16, 33001), (640, 2, 200, 33001),
-       (17, 4, 8, 50000), (100, 3, 64, 32769)]
+       (17, 4, 8, 50000), (100, 3, 64, 32769), (1280, 2, 500, 33001)]
 
 
 @pytest.mark.parametrize("K0,nlayers,nhid,B", BIG)
@@ -65,6 +68,9 @@ def test_mlp_head_matches_float64_evaluation_on_both_block_sizes(K0, nlayers, nh
 def test_mlp_head_matches_float64_evaluation(K0, nlayers, nhid, B):
     m = _make_head(K0, nlayers, nhid, seed=K0 + nhid).to(DEV)
     assert m._hip_plan() is not None and "armnet_mlp_head_f32" in m.eval_path()
+    if nhid > 256:                                         # sliced: every launch at most 256 units wide
+        assert all(n1 - n0 <= 256 and n == 1 for _, n, _, n0, n1 in m._hip_plan())
+        assert [hf for _, _, hf, _, _ in m._hip_plan() if hf] == [1] + [2] * ((len(m._hip_plan()) // nlayers) - 1)
     g = torch.Generator().manual_seed(B)
     x = (torch.rand(B, K0, generator=g) * 3.0 - 1.0).to(DEV)           # post-BatchNorm neurons: O(1), both signs
     want = _ref64(m, x).cpu().numpy()

