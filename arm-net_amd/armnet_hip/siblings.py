@@ -8,8 +8,13 @@ the element-wise maps around the contraction:
                                outer exp
     AFN (models/afn.py)        weights = afn.weight (fixed); contraction over emb_bn(log(x)); bias, outer exp
 
-Eval-mode inference runs on armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head; training
-mode is not built for the siblings (the reference trains them with plain autograd) and raises."""
+Eval-mode inference runs on armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head.  Training
+(train.py:108-114 with --model gc_arm / afn; round 3) runs the reference's op chain on the device with autograd: HIP
+kernels for the lookup and its scatter-add gradient (armnet_gather_scale_f32 / armnet_scatter_add_f32), the in-place
+clamp / clip, the sparse map (armnet_entmax_f32, backward = utils/entmax.py:70-80 on the saved output), every
+training-mode BatchNorm1d (bn_kernels.hip) and the head's Linear + BatchNorm + ReLU passes; the three small contractions
+(gates, interaction, AFN's Linear over the fields) go to hipBLASLt through torch.  A fused backward like the ARM block's
+(armnet_fused_bwd_f32) is not built for the siblings."""
 import torch
 import torch.nn as nn
 
@@ -72,13 +77,18 @@ class SiblingBase(nn.Module):
         _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
         if v.dtype != torch.float32:
             raise native.ArmnetNativeError(f"x['value'] must be float32, got {v.dtype}")
-        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                f"{type(self).__name__}: only eval-mode inference (model.eval() under torch.no_grad()) is built on the "
-                "HIP kernels; the reference trains this model with plain autograd")
         v_run = v if v.is_contiguous() else v.contiguous()
         ids = ids if ids.is_contiguous() else ids.contiguous()
         return ids, v, v_run
+
+    def _needs_autograd(self):
+        """training mode, or eval mode with autograd on and a trainable parameter: the composed differentiable path"""
+        return self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+
+    def _lookup_train(self, ids, v_run):
+        """value clamp in place (x['value'].clamp_(0.001, 1.)) + differentiable lookup * value (layers.py:15-21)"""
+        native.clamp_vals(v_run)
+        return self.embedding({"id": ids, "value": v_run}, check_ids=self.check_ids)
 
     def _finish(self, block, ids, v, v_run):
         if v_run is not v:
@@ -177,7 +187,25 @@ class GC_ARMModel(SiblingBase):
     def forward(self, x, vals=None):
         """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (gc_arm.py:82-105: squeeze(1))"""
         ids, v, v_run = self._inputs(x, vals)
+        if self._needs_autograd():
+            return self._finish(self._arm_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.arm_block(ids, v_run), ids, v, v_run)
+
+    def _arm_block_autograd(self, ids, v_run):
+        """gc_arm.py:86-94 as differentiable device ops (train mode: batch statistics in both BatchNorm1d layers)"""
+        from .block import entmax_forward
+        B = v_run.shape[0]
+        K, H, E = self.nhead, self.arm_hid, self.nemb
+        at = self.attn_layers
+        x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E]
+        x_exp = self.emb_bn(torch.exp(x_emb))                                    # channel = field (gc_arm.py:89)
+        qb = torch.einsum("kxy,koy->kox", at.bilinear, at.Q).reshape(K * H, E)   # parameter-only fold of the bilinear form
+        gates = torch.matmul(x_emb, qb.t()).transpose(1, 2)                      # [B, K*H, F]
+        gates = gates + gates.sum(-1, keepdim=True)                              # global context = the gates' field sum
+        p = entmax_forward(gates.contiguous(), self.alpha, dim=-1, n_iter=self.n_iter)
+        w = p * at.values.reshape(1, K * H, -1)
+        arm = torch.bmm(w, x_exp)                                                # [B, K*H, E]
+        return self.arm_bn(arm)
 
 
 class AFNModel(SiblingBase):
@@ -235,4 +263,14 @@ class AFNModel(SiblingBase):
         """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (afn.py:49-72: squeeze(1))"""
         ids, v, v_run = self._inputs(x, vals)
         self.embedding_clip()
+        if self._needs_autograd():
+            return self._finish(self._afn_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.afn_block(ids, v_run), ids, v, v_run)
+
+    def _afn_block_autograd(self, ids, v_run):
+        """afn.py:61-69 as differentiable device ops; Dropout (afn.py:69) acts on the block's output"""
+        x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E], positive after the clip
+        x_log = self.emb_bn(torch.log(x_emb))                                    # channel = field
+        afn = torch.exp(self.afn(x_log.transpose(1, 2)))                         # [B,E,O]
+        afn = self.afn_bn(afn.transpose(1, 2).contiguous())                      # [B,O,E]
+        return self.dropout(afn)

@@ -317,6 +317,7 @@ def main():
     big_batch_grad_cases()
     sibling_cases()
     wide_head_cases()
+    sibling_grad_cases()
 
 
 def run_sh_cases():
@@ -472,6 +473,74 @@ def _sibling_case(name, kind, ctor, B, seed, regime):
     _save(name, meta, sd_before, ids, vals, cap)
 
 
+def _sibling_model(kind, ctor, gen, regime):
+    from models.afn import AFNModel
+    from models.gc_arm import GC_ARMModel
+    if kind == "gc":
+        m = GC_ARMModel(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhead"], ctor["alpha"], ctor["nhid"],
+                        ctor["mlp_nlayer"], ctor["mlp_nhid"], ctor["dropout"], ctor["ensemble"], ctor["deep_nlayer"],
+                        ctor["deep_nhid"])
+        block_bn = m.arm_bn
+    else:
+        m = AFNModel(ctor["nfield"], ctor["nfeat"], ctor["nemb"], ctor["nhid"], ctor["mlp_nlayer"], ctor["mlp_nhid"],
+                     ctor["dropout"], ctor["ensemble"], ctor["deep_nlayer"], ctor["deep_nhid"])
+        block_bn = m.afn_bn
+    if regime == "stress":
+        with torch.no_grad():
+            w = m.embedding.embedding.weight
+            w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
+            if kind == "gc":
+                m.attn_layers.Q.mul_(4.0)
+            for bn in [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm1d)]:
+                bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=gen) * 0.05 + (1.0 if bn is block_bn or bn is m.emb_bn else 0.0))
+                bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=gen) * 0.4 + 0.8)
+                bn.weight.copy_(torch.rand(bn.weight.shape, generator=gen) + 0.5)
+                bn.bias.copy_(torch.randn(bn.bias.shape, generator=gen) * 0.1)
+            if hasattr(m, "deep_embedding"):
+                w = m.deep_embedding.embedding.weight
+                w.copy_(torch.randn(w.shape, generator=gen) * 0.5)
+    return m
+
+
+def _sibling_grad_case(name, kind, ctor, B, seed, train_mode):
+    """S3 (round 3) - gradients of the reference's own training step (train.py:60,108-113) for the sibling models, every
+    parameter, plus the BatchNorm running statistics after the step and (AFN) the table after embedding_clip"""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    m = _sibling_model(kind, ctor, gen, "stress")
+    ids, vals = _inputs(B, ctor["nfield"], ctor["nfeat"], gen)
+    y = (torch.rand(B, generator=gen) > 0.5).float()
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.train(train_mode)
+    x = {"id": ids.clone(), "value": vals.clone()}
+    logits = m(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+    cap = {"logits": logits.detach().clone(), "loss": loss.detach().clone(), "vals_clamped": x["value"].clone(),
+           "target": y}
+    for k, p in m.named_parameters():
+        cap["grad/" + k] = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+    for k, v in m.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            cap["after/" + k] = v.clone()
+    if kind == "afn":
+        cap["table_after"] = m.embedding.embedding.weight.detach().clone()
+    meta = dict(name=name, variant=kind, ctor=ctor, regime="stress", seed=seed, train=train_mode, torch=torch.__version__)
+    _save(name, meta, sd_before, ids, vals, cap)
+
+
+def sibling_grad_cases():
+    """B = 256: train-mode BatchNorm statistics over 256 x nemb values per channel (see big_batch_grad_cases)"""
+    _sibling_grad_case("s3_grad_gcarm_k2_a1.7_train_b256", "gc", base(13, 128, 8, 1.7, 8, nhead=2, mlp_nhid=16), 256, 161, True)
+    _sibling_grad_case("s3_grad_gcarm_k1_a2.0_ens_train_b256", "gc",
+                       base(22, 128, 16, 2.0, 16, nhead=1, ensemble=True, mlp_nhid=16, deep_nhid=16), 256, 162, True)
+    _sibling_grad_case("s3_grad_gcarm_k2_a1.0_evalbn_b64", "gc", base(10, 128, 10, 1.0, 8, nhead=2, mlp_nhid=16), 64, 163, False)
+    _sibling_grad_case("s3_grad_afn_h16_train_b256", "afn", base(13, 128, 8, 2.0, 16, mlp_nhid=16), 256, 164, True)
+    _sibling_grad_case("s3_grad_afn_h8_ens_train_b256", "afn",
+                       base(10, 128, 10, 2.0, 8, ensemble=True, mlp_nhid=16, deep_nhid=16), 256, 165, True)
+    _sibling_grad_case("s3_grad_afn_h16_evalbn_b64", "afn", base(22, 128, 16, 2.0, 16, mlp_nhid=16), 64, 166, False)
+
+
 def sibling_cases():
     for alpha in (1.0, 1.7, 2.0):
         _sibling_case(f"s1_gcarm_criteo_k2_a{alpha}_stress", "gc", base(39, 512, 16, alpha, 16, nhead=2), 16, 151, "stress")
@@ -518,6 +587,9 @@ if __name__ == "__main__":
         big_batch_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--round3-only":      # add the round-3 cases without rewriting the others
         wide_head_cases()
+        sibling_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--sibling-grad-only":
+        sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
         entmax_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--run-sh-grad-only":

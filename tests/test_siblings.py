@@ -68,12 +68,89 @@ def test_product_module_has_the_reference_state_dict(name):
     assert list(m.state_dict().keys()) == list(sd.keys())
 
 
-def test_training_mode_is_refused_loudly():
+def test_cpu_tensors_are_refused_loudly():
+    """no CPU fallback: a model or batch that is not on the GPU raises (training and inference alike)"""
+    from armnet_hip import native
     meta, sd, ids, vals, _ = load("s2_afn_frappe_h10_ens_stress")
     m = _build(meta, sd)
-    m.train()
-    with pytest.raises((NotImplementedError, Exception)):
-        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
+    for mode in (True, False):
+        m.train(mode)
+        with pytest.raises(native.ArmnetNativeError):
+            m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
+
+
+GRAD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s3_grad_*.npz")))
+
+
+def test_sibling_gradient_fixtures_are_present():
+    assert sum("gcarm" in n for n in GRAD_CASES) >= 3 and sum("afn" in n for n in GRAD_CASES) >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_sibling_training_step_matches_reference_gradients(name):
+    """round-2 verdict, missing 3 / next 9: `train.py --model gc_arm | afn` (train.py:108-114: BCEWithLogitsLoss,
+    backward) on the device — every parameter's gradient against the reference's own step (captured by
+    tests/golden/make_golden.py), the BatchNorm running statistics after the step, AFN's clipped table"""
+    meta, sd, ids, vals, ref = load(name)
+    m = _build(meta, sd, DEV)
+    m.train(meta["train"])
+    x = {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+    y = torch.from_numpy(ref["target"]).to(DEV)
+    logits = m(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+
+    def close(got, want, rtol):
+        want = np.asarray(want, dtype=np.float64)
+        return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - want))) / max(float(np.abs(want).max()), 1e-12) <= rtol
+
+    assert tuple(logits.shape) == ref["logits"].shape
+    assert close(logits.detach().cpu().numpy(), ref["logits"], 2e-5), "logits"
+    assert abs(float(loss.detach()) - float(ref["loss"])) <= 2e-6
+    np.testing.assert_array_equal(x["value"].cpu().numpy(), ref["vals_clamped"])
+    if "table_after" in ref:
+        np.testing.assert_array_equal(m.embedding.embedding.weight.detach().cpu().numpy(), ref["table_after"])
+    gmax = max(float(np.abs(ref["grad/" + k]).max()) for k, _ in m.named_parameters())
+    worst = {}
+    for k, p in m.named_parameters():
+        g = ref["grad/" + k]
+        if float(np.abs(g).max()) < 1e-6 * gmax:
+            continue          # analytically zero (a bias in front of a train-mode BatchNorm): rounding noise
+        assert p.grad is not None, k
+        worst[k] = float(np.max(np.abs(p.grad.cpu().numpy().astype(np.float64) - g))) / max(float(np.abs(g).max()), 1e-12)
+    print(name, {k: f"{v:.1e}" for k, v in worst.items() if v > 1e-5})
+    for k, err in worst.items():
+        assert err <= 5e-5, f"grad of {k}: rel err {err:.2e}"
+    if meta["train"]:
+        got = m.state_dict()
+        for k in [k for k in ref if k.startswith("after/") and "running_" in k]:
+            np.testing.assert_allclose(got[k[6:]].cpu().numpy(), ref[k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gc", "afn"])
+def test_sibling_adam_steps_reduce_the_loss(kind):
+    """train.py-shaped loop: Adam + per-parameter gradient clamp hooks (train.py:61-65)"""
+    name = "s3_grad_gcarm_k2_a1.7_train_b256" if kind == "gc" else "s3_grad_afn_h16_train_b256"
+    meta, sd, ids, vals, ref = load(name)
+    m = _build(meta, sd, DEV).train()
+    for p in m.parameters():
+        p.register_hook(lambda g: g.clamp(-1.0, 1.0))
+    opt = torch.optim.Adam(m.parameters(), lr=3e-3)
+    idt, y = torch.from_numpy(ids).to(DEV), torch.from_numpy(ref["target"]).to(DEV)
+    losses = []
+    for _ in range(25):
+        loss = torch.nn.BCEWithLogitsLoss()(m({"id": idt, "value": torch.from_numpy(vals.copy()).to(DEV)}), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0], losses
+    m.eval()                                               # and the trained weights serve through the fused kernels
+    with torch.no_grad():
+        yy = m({"id": idt, "value": torch.from_numpy(vals.copy()).to(DEV)})
+    assert bool(torch.isfinite(yy).all())
 
 
 @pytest.mark.gpu
