@@ -115,8 +115,11 @@ def test_sibling_training_step_matches_reference_gradients(name):
     worst = {}
     for k, p in m.named_parameters():
         g = ref["grad/" + k]
-        if float(np.abs(g).max()) < 1e-6 * gmax:
-            continue          # analytically zero (a bias in front of a train-mode BatchNorm): rounding noise
+        if float(np.abs(g).max()) < 1e-5 * gmax:
+            # analytically zero up to the BatchNorm eps: a bias in front of a train-mode BatchNorm, and afn.bias, which
+            # scales exp(.) per channel right in front of afn_bn (2e-7 against gradients of 1e-1: cancellation noise in
+            # the reference's own fp32 step)
+            continue
         assert p.grad is not None, k
         worst[k] = float(np.max(np.abs(p.grad.cpu().numpy().astype(np.float64) - g))) / max(float(np.abs(g).max()), 1e-12)
     print(name, {k: f"{v:.1e}" for k, v in worst.items() if v > 1e-5})
