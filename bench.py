@@ -524,17 +524,23 @@ def main():
             tfl = flops / (k_ms * 1e-3) / 1e12
             traffic, tag, ceil_us, ceil_src = committed_measurements(a, regime)
             fr = {"hbm": achieved / HBM_PEAK_GBS, "mfma_fp32": tfl / FP32_MFMA_PEAK_TFLOPS,
-                  "access_pattern_ceiling": (ceil_us * 1e-3 / k_ms) if ceil_us else None}
+                  "access_pattern_ceiling": (ceil_us * 1e-3 / k_ms) if ceil_us else None,
+                  # the bytes the fabric really moves (PMC, 128 bytes per read request: a random 64-byte row costs a
+                  # whole 128-byte line) over the same kernel time, against the same 8 TB/s
+                  "hbm_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tag,
                     "kernel": "armnet::fused_mfma_kernel", "kernel_ms": k_ms,
                     "alg_bytes_per_sample": read_b + write_b, "alg_bytes_per_launch": alg_bytes,
                     "folded_tflops": tfl, "fractions": fr,
                     "access_pattern_ceiling_us": ceil_us, "access_pattern_ceiling_source": ceil_src,
-                    # which limit binds: DESIGN.md §4 — fp32 MFMA cycles ADD to the VALU cycles of a SIMD, so the
-                    # kernel is bound by instruction issue (VALU + MFMA), above both the HBM and the flop floors
-                    "binding_limit": "issue (fp32 MFMA + VALU cycles add on a SIMD); neither the HBM nor the "
-                                     "MFMA roofline binds: see fractions"}
+                    # which limit binds: the memory system's REQUEST rate and instruction issue, together.
+                    # A random 64-byte row costs one 128-byte fabric request — 47-55 G requests/s whatever the payload
+                    # (profiles/r03_fetch_size_calibration_gather_rows.txt) — so this launch's ~3.9 M requests cannot
+                    # finish in under ~70 us (`access_pattern_ceiling`); on the issue side fp32 MFMA cycles ADD to the
+                    # VALU cycles of a SIMD (~63 us of pure issue).  Neither byte nor flop roofline is reached.
+                    "binding_limit": "memory-request rate (one 128-byte request per random 64-byte row) + instruction "
+                                     "issue (fp32 MFMA and VALU cycles add on a SIMD); see fractions"}
 
         def regime_obj(regime):
             w_ms, e_ms, f_ms = res[regime][:3]

@@ -48,7 +48,7 @@ def test_single_gpu_line_has_the_contract_keys_and_both_objects():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0
-    assert set(r["fractions"]) == {"hbm", "mfma_fp32", "access_pattern_ceiling"}
+    assert set(r["fractions"]) == {"hbm", "mfma_fp32", "access_pattern_ceiling", "hbm_traffic"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "samples/s" and c["sample"]
     assert set(d["regimes"]) == {"fresh", "stress"}

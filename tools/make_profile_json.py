@@ -31,22 +31,33 @@ def main(prof_dir, gs_log, tag):
     import bench
     fetch_kib, n1 = counter_mean(os.path.join(prof_dir, "pmc_fetch"), "FETCH_SIZE", "fused_mfma_kernel")
     write_kib, n2 = counter_mean(os.path.join(prof_dir, "pmc_write"), "WRITE_SIZE", "fused_mfma_kernel")
+    rdreq, n3 = counter_mean(os.path.join(prof_dir, "pmc_rdreq"), "TCC_EA0_RDREQ_sum", "fused_mfma_kernel")
+    rd32, _ = counter_mean(os.path.join(prof_dir, "pmc_rdreq"), "TCC_EA0_RDREQ_32B_sum", "fused_mfma_kernel")
     B, F, E, O = 65536, 39, 16, 32
-    stream = B * F * 12                       # ids int64 + vals: wide coalesced streams, tallied at half their bytes
+    # Calibration (profiles/r03_fetch_size_calibration_gather_rows.txt, tools/ubench/gather_calib.hip): on gfx950 one
+    # fabric read request of the "large" class moves a 128-byte line — a coalesced stream issues 0.5 requests per 64
+    # bytes, a random 64-BYTE row ONE request, a random 128-byte row ONE request, a 256-byte row two — and FETCH_SIZE
+    # tallies every such request at 64 bytes (TCC_EA0_RDREQ_32B, the small class, stays 0).  The bytes the fabric moves
+    # are therefore 128 x TCC_EA0_RDREQ (= 2 x FETCH_SIZE) for EVERY read of this kernel, the half-used lines of the
+    # 64-byte row gathers included.  WRITE_SIZE matched the written bytes to 0.02 % in rounds 1-2 (1-KiB contiguous
+    # stores per wave instruction) and is taken as is.
+    read_bytes = 128.0 * rdreq if rdreq else 2.0 * fetch_kib * 1024
     entry = {
         "workload": f"nfield={F} nemb={E} nhid={O} nhead=1 B={B} alpha=2.0 ids=uniform regime=fresh rotate=4",
         "kernel_src_sha": bench.kernel_src_sha(),
-        "source": f"profiles/{tag}_bench_n1_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                  f"{n1}/{n2} dispatches of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --regime fresh --in-flight 1 --settle-ms 0`)",
-        "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
+        "source": f"profiles/{tag}_bench_n1_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / TCC_EA0_RDREQ_sum / WRITE_SIZE, "
+                  f"separate passes, {n1}/{n3}/{n2} dispatches of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                  f"--regime fresh --in-flight 1 --settle-ms 0`)",
+        "fetch_size_kib": fetch_kib, "write_size_kib": write_kib, "tcc_ea0_rdreq": rdreq, "tcc_ea0_rdreq_32b": rd32,
         "fetch_bytes_raw": fetch_kib * 1024, "write_bytes": write_kib * 1024,
-        "stream_halving_correction_bytes": stream // 2,
-        "traffic_bytes_per_launch": int(fetch_kib * 1024 + stream // 2 + write_kib * 1024),
+        "read_bytes_at_128_per_request": read_bytes,
+        "traffic_bytes_per_launch": int(read_bytes + write_kib * 1024),
         "algorithmic_bytes_per_launch": B * (F * (12 + 4 * E) + 4 * O * E),
-        "_comment": "gfx950 tallies wide coalesced 16-byte-per-lane streams at half their bytes (MI355X_MICROARCH.md, "
-                    "HBM): the ids + vals streams are such reads, the 64-byte row gathers are not, hence the correction "
-                    "term; the steps rotate over 4 distinct batches (660 MB), so only the 64 MB table can be served "
-                    "from the Infinity Cache (FETCH_SIZE counts fabric-side requests, cache hits included)",
+        "_comment": "read traffic = 128 bytes x TCC_EA0_RDREQ (calibrated: profiles/r03_fetch_size_calibration_gather_rows.txt): "
+                    "a random 64-byte embedding row costs one 128-byte request, exactly like a 128-byte row, so the "
+                    "2.56 M row gathers of a launch move 327 MB of lines for 164 MB of rows; the steps rotate over 4 "
+                    "distinct batches (660 MB), so only the 64 MB table can be served from the Infinity Cache (the "
+                    "counters are fabric-side: cache hits included)",
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump({"entries": [entry]}, f, indent=1)

@@ -17,10 +17,16 @@ run() { # name, extra args...
 }
 CMD=("$@")
 run trace --stats
+if [ -n "${PROFILE_LIGHT:-}" ]; then   # PROFILE_LIGHT=1: timings + the first SQ pass only (second weight regime)
+  run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+  exit 0
+fi
 run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run pmc_sq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_WAIT_INST_LDS
 run pmc_sq3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL
 run pmc_fetch --pmc FETCH_SIZE
+run pmc_rdreq --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+run pmc_wrreq --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run pmc_write --pmc WRITE_SIZE
 run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT
