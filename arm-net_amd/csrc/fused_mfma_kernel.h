@@ -45,6 +45,7 @@ static __device__ float kZeroRow[4] = {0.f, 0.f, 0.f, 0.f};   // not const: keep
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // 4-byte aligned views for global memory: gfx950 runs in unaligned access mode, so these still compile to ONE
 // global_load/store_dwordx4 / dwordx2 (rows of nemb floats are only 4-byte aligned when nemb is odd)
 typedef f32x4 f32x4u __attribute__((aligned(4)));
@@ -86,6 +87,22 @@ __device__ __forceinline__ float vadd(float a, float b) {
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+
+// Read-once inputs (ids, values) and the write-once output with the non-temporal hint, so that they do not displace the
+// embedding table — the only data this kernel reuses — from the L2 / Infinity Cache (developer switch ARMNET_NT_IO)
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#ifdef ARMNET_NT_IO
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+#ifdef ARMNET_NT_IO
+#define ARMNET_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define ARMNET_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#endif
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS traffic of one wave is serviced in issue order; this only stops the COMPILER from moving
@@ -281,11 +298,11 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 for (int n = 0; n < NI; ++n) {
                     const uint32_t o = decltype(is_short)::value ? lane_off(n, true) : off4[n];
                     if constexpr (SRC == 0) {
-                        const uint2 w = *reinterpret_cast<const uint2*>(ids_g + (o << 1));
-                        raw_lo[n] = w.x;
-                        raw_hi[n] = w.y;
+                        const u32x2 w = stream_load(reinterpret_cast<const u32x2*>(ids_g + (o << 1)));
+                        raw_lo[n] = w[0];
+                        raw_hi[n] = w[1];
                     } else {
-                        raw_lo[n] = *reinterpret_cast<const uint32_t*>(ids_g + o);
+                        raw_lo[n] = stream_load(reinterpret_cast<const uint32_t*>(ids_g + o));
                         raw_hi[n] = 0u;
                     }
                 }
@@ -311,7 +328,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
                 const uint32_t o = decltype(is_short)::value ? lane_off(n, true) : off4[n];
-                val_cur[n] = *reinterpret_cast<const float*>(vals_g + o);
+                val_cur[n] = stream_load(reinterpret_cast<const float*>(vals_g + o));
                 const char* src;
                 if constexpr (FROM_ROWS) {
                     src = row_base + (size_t)(e0 + (o >> 2)) * row_bytes;
@@ -807,7 +824,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                             const f32x2 vhi = __builtin_elementwise_fma(ehi, bn0, bn1);
                             const int e = 16 * eb + 4 * g;
                             if (fast_store) {
-                                *reinterpret_cast<f32x4u*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
+                                ARMNET_STREAM_STORE(reinterpret_cast<f32x4u*>(dst + 16 * eb), (f32x4{vlo[0], vlo[1], vhi[0], vhi[1]}));
                             } else if (o_ok) {
                                 if (e + 4 <= Er) {
                                     *reinterpret_cast<f32x4u*>(dst + 16 * eb) = f32x4{vlo[0], vlo[1], vhi[0], vhi[1]};
