@@ -882,7 +882,11 @@ static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, 
 // nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
 template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
 static int launch_one(const FusedArgs& a, hipStream_t st) {
+#ifdef ARMNET_FORCE_SPW1                    // developer probe: one sample per wave-group everywhere (half-pad last tile)
+    constexpr int SPW = 1;
+#else
     constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
+#endif
     // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
     // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
     // generic-alpha Newton keeps two transcendental temporaries per pair alive)
