@@ -390,7 +390,10 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     fetch_raw(grp + nwaves);
 #ifdef ARMNET_PHASE_TIMING
     // developer build: per-phase s_memtime deltas, summed over all waves into id_status[0..7] (as uint32)
-    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+    // 0: what is left of the staging phase, 1: MFMA #1, 2: row statistics, 3: solver, 4: weights + MFMA #2, 5: epilogue + stores,
+    // 6: wait for the group's rows, 7: staging (clamp, scale, LDS writes), 8: wait for the next group's ids,
+    // 9: ISSUE of its value / row loads, 10: ISSUE of the id loads of the group after
+    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph_t = __builtin_amdgcn_s_memtime();
 #define PHASE(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ph_acc[i] += _n - ph_t; ph_t = _n; } while (0)
 #else
@@ -407,6 +410,11 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         const int b0 = grp * SPW;
         // ---- stage the current group's rows (scaled) into the wave's LDS tile -----------------------
         wave_lds_fence();
+#ifdef ARMNET_PHASE_TIMING
+#pragma unroll
+        for (int n = 0; n < NI; ++n) asm volatile("" : "+v"(rows_cur[n]), "+v"(val_cur[n]));    // all of this group's loads have landed
+        PHASE(6);
+#endif
         bool changed = false;
         float vcl[NI];
 #pragma unroll
@@ -450,8 +458,23 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
             }
         }
         // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
+#ifdef ARMNET_PHASE_TIMING
+        wave_lds_fence();
+        PHASE(7);
+        if constexpr (!FROM_ROWS) {
+#pragma unroll
+            for (int n = 0; n < NI; ++n) asm volatile("" : "+v"(raw_lo[n]), "+v"(raw_hi[n]));        // the ids have landed
+        }
+        PHASE(8);
+#endif
         issue_rows_vals(grp + nwaves);
+#ifdef ARMNET_PHASE_TIMING
+        PHASE(9);
+#endif
         fetch_raw(grp + 2 * nwaves);
+#ifdef ARMNET_PHASE_TIMING
+        PHASE(10);
+#endif
         wave_lds_fence();
         PHASE(0);
 
@@ -854,7 +877,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     }
 #ifdef ARMNET_PHASE_TIMING
     if (lane == 0 && a.id_status)
-        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned int*>(a.id_status) + i, (unsigned int)(ph_acc[i] >> 4));
+        for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned int*>(a.id_status) + i, (unsigned int)(ph_acc[i] >> 4));
 #endif
 }
 

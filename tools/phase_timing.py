@@ -22,14 +22,16 @@ def main():
     sc = (torch.rand(O, generator=g) + 0.5).to(dev); sh = torch.randn(O, generator=g).to(dev)
     ids = torch.randint(0, nfeat, (B, F), generator=g).to(dev); vals = torch.rand(B, F, generator=g).to(dev)
     out = torch.empty(B, O, E, device=dev)
-    st = torch.zeros(8, device=dev, dtype=torch.int32)
+    st = torch.zeros(16, device=dev, dtype=torch.int32)
     for _ in range(3):
         native.fused_fwd(B, F, E, O, alpha, 50, flags, ids, vals, table, qf, values, sc, sh, out, None)
     torch.cuda.synchronize()
     native.fused_fwd(B, F, E, O, alpha, 50, flags, ids, vals, table, qf, values, sc, sh, out, st)
     torch.cuda.synchronize()
-    v = st.cpu().numpy().astype("uint32").astype(float)[:6]
-    names = ["stage+issue loads", "MFMA#1 (+A reads)", "setup (sum,max,LDS reduce)", "newton loop", "final w + MFMA#2", "epilogue+store"]
+    v = st.cpu().numpy().astype("uint32").astype(float)[:11]
+    names = ["rest of the staging phase", "MFMA#1 (+A reads)", "setup (sum,max,LDS reduce)", "newton loop", "final w + MFMA#2", "epilogue+store",
+             "wait for the group's rows", "staging (clamp, scale, LDS writes)", "wait for the next group's ids",
+             "issue value + row loads of the next group", "issue id loads of the group after"]
     tot = v.sum()
     for n, x in zip(names, v):
         print(f"{n:28s} {100 * x / tot:5.1f} %")
