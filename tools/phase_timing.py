@@ -12,7 +12,8 @@ def main():
     alpha = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
     regime = sys.argv[2] if len(sys.argv) > 2 else "fresh"
     flags = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
-    B, F, E, O, nfeat = 65536, 39, 16, 32, 1_000_000
+    O = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    B, F, E, nfeat = 65536, 39, 16, 1_000_000
     dev = "cuda:0"
     g = torch.Generator().manual_seed(1)
     bound = (6.0 / (nfeat + E)) ** 0.5
@@ -35,6 +36,6 @@ def main():
     tot = v.sum()
     for n, x in zip(names, v):
         print(f"{n:28s} {100 * x / tot:5.1f} %")
-    print("alpha", alpha, regime, "flags", hex(flags))
+    print("alpha", alpha, regime, "flags", hex(flags), "neurons", O)
 
 main()
