@@ -79,6 +79,11 @@ int main(int argc, char** argv) {
         printf("%-34s blocks=%5d store=%d : %7.1f us  %6.0f GB/s\n", name, blocks, st, ms * 1e3,
                (bytes_rd + (st ? bytes_wr : 0)) / ms / 1e6);
     };
+    if (argc > 2) {                    // `gather_stream <rot> quick`: the two configurations bench.py quotes live
+        run(k<1>, 512, 1, "depth1 (1 group of loads in flight)");
+        run(k<1>, 1024, 1, "depth1 (1 group of loads in flight)");
+        return 0;
+    }
     for (int st : {1, 0}) {
         for (int blocks : {512, 1024, 2048, 4096}) {
             run(k<1>, blocks, st, "depth1 (1 group of loads in flight)");
