@@ -16,6 +16,45 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
     return x;
 }
 
+// the same 16-byte load with a cache-policy modifier (POL: 0 default, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc0 nt,
+// 7 sc1 nt): does any of them make the L2 ask the fabric for LESS than a whole 128-byte line per 64-byte row?
+template <int POL>
+__device__ __forceinline__ f32x4 load16(const float* p) {
+    f32x4 v;
+    if constexpr (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 7) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int POL>
+__global__ void __launch_bounds__(256) gather_only_pol(const float* __restrict__ table, float* sink, unsigned nfeat,
+                                                       unsigned rows, unsigned salt) {
+    constexpr int LPR = 4;                                   // 64-byte rows
+    const unsigned tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    const unsigned chunk = tid % LPR;
+    f32x4 acc = {0, 0, 0, 0};
+    for (unsigned r = tid / LPR; r < rows; r += 4 * (nthreads / LPR)) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned rr = r + u * (nthreads / LPR);
+            if (rr >= rows) rr = rows - 1;
+            const unsigned id = hash32(rr * 2654435761u + salt) % nfeat;
+            v[u] = load16<POL>(table + (size_t)id * (LPR * 4) + chunk * 4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    if (acc[0] == 12345.f) sink[0] = acc[1] + acc[2] + acc[3];
+}
+
 template <int LPR>   // lanes per row (row_bytes / 16)
 __global__ void __launch_bounds__(256) gather_only(const float* __restrict__ table, float* sink, unsigned nfeat,
                                                    unsigned rows, unsigned salt) {
@@ -50,12 +89,24 @@ int main(int argc, char** argv) {
     const unsigned nfeat = argc > 2 ? (unsigned)atoll(argv[2]) : 1000000u;
     const unsigned rows = argc > 3 ? (unsigned)atoll(argv[3]) : 2555904u;    // 65536 x 39
     const int launches = argc > 4 ? atoi(argv[4]) : 20;
+    const int pol = argc > 5 ? atoi(argv[5]) : -1;           // >= 0: 64-byte rows through load16<pol>
     float *table, *sink;
     const size_t tbytes = (size_t)nfeat * row_bytes;
     hipMalloc(&table, tbytes); hipMemset(table, 0, tbytes); hipMalloc(&sink, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&](int i) {
-        if (stream) stream_only<<<4096, 256>>>(table, sink, (size_t)rows * 64 / 16 < tbytes / 16 ? (size_t)rows * 4 : tbytes / 16);
+        if (pol >= 0) {
+            switch (pol) {
+                case 0: gather_only_pol<0><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 1: gather_only_pol<1><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 2: gather_only_pol<2><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 3: gather_only_pol<3><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 4: gather_only_pol<4><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 5: gather_only_pol<5><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                case 6: gather_only_pol<6><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+                default: gather_only_pol<7><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i); break;
+            }
+        } else if (stream) stream_only<<<4096, 256>>>(table, sink, (size_t)rows * 64 / 16 < tbytes / 16 ? (size_t)rows * 4 : tbytes / 16);
         else if (row_bytes == 64) gather_only<4><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i);
         else if (row_bytes == 128) gather_only<8><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i);
         else gather_only<16><<<2048, 256>>>(table, sink, nfeat, rows, 977u * i);
@@ -66,6 +117,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < launches; ++i) launch(100 + i);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= launches;
+    if (pol >= 0) printf("POLICY %d (0 default, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc0 nt, 7 sc1 nt): ", pol);
     printf("%s row_bytes=%d nfeat=%u (table %.0f MB) rows/launch=%u: %.1f us per launch, %.2f G rows/s, %.0f GB/s of row payload\n",
            stream ? "STREAM" : "GATHER", row_bytes, nfeat, tbytes / 1e6, rows, ms * 1e3, rows / ms / 1e6,
            (double)rows * row_bytes / ms / 1e6);
