@@ -194,3 +194,57 @@ def test_table_larger_than_4gib_every_lookup_path_against_the_oracle():
     want = orc.arm_block("1h", inv.reshape(B, F).astype(np.int64), v, sd, 2.0)
     np.testing.assert_array_equal(vs["i64"].cpu().numpy(), v)
     assert_close(outs["i64"].cpu().numpy(), want, TOL, "5.12 GB table")
+
+
+@pytest.mark.parametrize("alpha,regime", [(2.0, "stress"), (1.7, "fresh")])
+def test_full_size_properties_of_the_block(alpha, regime):
+    """Size-independent properties at BASELINE.json's full headline size (B = 65 536), where the oracle is too slow to
+    cover everything: the block treats samples independently, so (i) a permutation of the samples permutes the output
+    rows, bit for bit, whichever wave / group / pipeline slot a sample lands in; (ii) the batch cut into pieces (ragged
+    ones: short last groups) gives the same rows; (iii) the in-place clamp is idempotent — a second call on the clamped
+    values changes neither them nor the output; (iv) the post-BatchNorm neurons are finite and a sample fed twice gives
+    identical rows."""
+    import bench
+    a = _bench_args(alpha=alpha, regime=regime, batch=65536)
+    model = bench.build_model(a, torch.device(DEV), regime=regime)
+    ids, vals, _, _ = bench.make_batch(a, 0, torch.device(DEV), 0)
+    vals = vals * 1.2 - 0.1                                   # some values outside [1e-3, 1]
+    with torch.no_grad():
+        v0 = vals.clone()
+        out = model.arm_block(ids, v0)
+        assert bool(torch.isfinite(out).all())
+        # (iii) idempotence of the clamp
+        v1 = v0.clone()
+        out_again = model.arm_block(ids, v1)
+        assert torch.equal(v1, v0) and torch.equal(out_again, out)
+        assert float(v0.min()) >= 1e-3 and float(v0.max()) <= 1.0
+        # (i) permutation of the samples
+        g = torch.Generator(device="cpu").manual_seed(5)
+        perm = torch.randperm(a.batch, generator=g).to(DEV)
+        vp = vals[perm].clone()
+        out_p = model.arm_block(ids[perm].contiguous(), vp)
+        assert torch.equal(out_p, out[perm]) and torch.equal(vp, v0[perm])
+        # (ii) the batch in ragged pieces
+        cuts = [0, 1, 4098, 20011, 40001, 65535, 65536]
+        pieces = [model.arm_block(ids[lo:hi].contiguous(), vals[lo:hi].clone()) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        assert torch.equal(torch.cat(pieces), out)
+        # (iv) one sample repeated through a whole batch
+        rep = model.arm_block(ids[:1].expand(4097, -1).contiguous(), vals[:1].expand(4097, -1).clone())
+        assert torch.equal(rep, out[:1].expand(4097, -1, -1))
+
+
+def test_full_size_forward_to_logits_is_sample_independent():
+    """the same through the prediction head (armnet_mlp_head_f32, 8-wave blocks at this batch, 4-wave blocks for the
+    pieces): logits of a permuted / cut batch equal the permuted / concatenated logits bit for bit"""
+    import bench
+    a = _bench_args(alpha=2.0, regime="stress", batch=65536)
+    model = bench.build_model(a, torch.device(DEV), regime="stress")
+    ids, vals, _, _ = bench.make_batch(a, 0, torch.device(DEV), 0)
+    with torch.no_grad():
+        y = model({"id": ids, "value": vals.clone()})
+        perm = torch.randperm(a.batch, generator=torch.Generator().manual_seed(6)).to(DEV)
+        yp = model({"id": ids[perm].contiguous(), "value": vals[perm].clone()})
+        assert torch.equal(yp, y[perm])
+        cuts = [0, 3, 8192, 33000, 65536]
+        ys = torch.cat([model({"id": ids[lo:hi].contiguous(), "value": vals[lo:hi].clone()}) for lo, hi in zip(cuts[:-1], cuts[1:])])
+        assert torch.equal(ys, y)
