@@ -236,3 +236,61 @@ def test_weight_update_and_bad_id_on_a_sharded_model_two_ranks_on_one_gpu(whole)
     for rank, oks, path in res:
         assert all(oks), f"rank {rank}: {oks} ({path})"
         assert path == ("whole_shards" if whole == "auto" else "fixed")
+
+
+def _worker_rccl_world1(port, q):
+    for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from golden_util import load
+        from model_util import build_model
+        dev = "cuda:0"
+        meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
+        c = meta["ctor"]
+        g = torch.Generator().manual_seed(77)
+        B = 517
+        ids = torch.randint(0, c["nfeat"], (B, c["nfield"]), generator=g).to(dev)
+        vals = torch.rand(B, c["nfield"], generator=g).to(dev)
+        m = build_model(meta, sd, dev)
+        res = {}
+        with torch.no_grad():
+            want = m.arm_block(ids, vals.clone())
+            m.shard_embedding()
+            assert not m._shard._via_host                       # device buffers straight into RCCL
+            for name, whole, dedup, proto in (("whole_shards", "auto", "auto", "fixed"), ("fixed", False, True, "fixed"),
+                                              ("fixed_nodedup", False, False, "fixed"), ("exact", False, True, "exact")):
+                m._shard.whole_shard, m._shard.dedup, m._shard.protocol = whole, dedup, proto
+                m._shard.slot_lookups = None
+                got = m.arm_block(ids, vals.clone())
+                res[name] = (bool(torch.equal(got, want)), m._shard.last_path)
+            bad = ids.clone()
+            bad[5, 5] = -3
+            try:
+                m.arm_block(bad, vals.clone())
+                res["bad_id"] = (False, None)
+            except IndexError:
+                res["bad_id"] = (True, None)
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_lookup_through_rccl_at_world_size_one():
+    """the RCCL ("nccl") code path itself — equal-split all_to_all_single of indices and rows, all_gather_into_tensor of the
+    shards, the flag all-reduce of poll(), the split-matrix all-gather of the exact protocol — on device buffers, at the
+    only world size one GPU allows; the results must be bit-equal to the replicated table's"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_world1, args=(29741, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res["whole_shards"] == (True, "whole_shards"), res
+    assert res["fixed"] == (True, "fixed") and res["fixed_nodedup"] == (True, "fixed") and res["exact"] == (True, "exact"), res
+    assert res["bad_id"][0], res
