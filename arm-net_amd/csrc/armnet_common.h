@@ -59,6 +59,11 @@ constexpr int kNewtonMaxIter = 40;
 #define ARMNET_NEWTON_TOL 6e-7f
 #endif
 constexpr float kNewtonTol = ARMNET_NEWTON_TOL;
+// ... or once the Newton step itself is this small (matrix-core forward kernel; see its solver loop)
+#ifndef ARMNET_NEWTON_TAU_TOL
+#define ARMNET_NEWTON_TAU_TOL 2e-7f
+#endif
+constexpr float kNewtonTauTol = ARMNET_NEWTON_TAU_TOL;
 
 // compute units of the current device (256 on MI355X), cached per device; 256 if the query fails
 int device_cu_count();
