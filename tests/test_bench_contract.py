@@ -54,6 +54,8 @@ def test_single_gpu_line_has_the_contract_keys_and_both_objects():
     assert set(d["regimes"]) == {"fresh", "stress"}
     # steady state is `value`; the cold-start run of the same steps and the two-batches-in-flight variant ride along
     assert d["config"]["clock_settle_ms"] > 0 and d["cold_start"]["value"] > 0
+    oa = d["other_alphas"]                                             # alpha = 1.7 and 1.5 beside the headline
+    assert set(oa) == {"1.7", "1.5", "note"} and oa["1.7"]["fresh"]["value"] > 1e6 and oa["1.5"]["stress"]["value"] > 1e6
     fl = d["batches_in_flight"]
     assert fl["n"] == 2 and fl["value"] > 0 and fl["full_forward_samples_per_s"] > 0
 

@@ -7,10 +7,10 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
-PMC_EXTRA="--settle-ms 0" bash tools/profile.sh r3_prof_fresh -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --regime fresh --in-flight 1
+PMC_EXTRA="--settle-ms 0" bash tools/profile.sh r3_prof_fresh -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-alphas --regime fresh --in-flight 1
 python tools/prof_summary.py gpurun_out/r3_prof_fresh fused > gpurun_out/r3_prof_fresh_summary.txt 2>&1
 python tools/prof_summary.py gpurun_out/r3_prof_fresh mlp_head >> gpurun_out/r3_prof_fresh_summary.txt 2>&1
-PROFILE_LIGHT=1 PMC_EXTRA="--settle-ms 0" bash tools/profile.sh r3_prof_stress -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --regime stress --in-flight 1
+PROFILE_LIGHT=1 PMC_EXTRA="--settle-ms 0" bash tools/profile.sh r3_prof_stress -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-alphas --regime stress --in-flight 1
 python tools/prof_summary.py gpurun_out/r3_prof_stress fused > gpurun_out/r3_prof_stress_summary.txt 2>&1
 cd "$ROOT"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o tools/ubench/gather_stream tools/ubench/gather_stream.hip && tools/ubench/gather_stream 4 > gpurun_out/r3_gather_stream.txt 2>&1
