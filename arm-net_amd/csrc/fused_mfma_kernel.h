@@ -681,9 +681,10 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     // they converge.  When the loop ends every row's S was evaluated at its final threshold.
                     // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
                     // at the final threshold), which saves the two transcendentals per element of a final pass
-                    // alpha = 2 with a 168-register budget (<= 3 waves/SIMD): the clamped differences of the last evaluation
-                    // are kept as well, which saves their recomputation in the weight pass
-                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && WPS <= 3);
+                    // alpha = 2 with a 168-register budget (<= 3 waves/SIMD), or one-sample groups at 5 waves/SIMD (half the
+                    // pairs: 94 registers): the clamped differences of the last evaluation are kept as well, which saves
+                    // their recomputation in the weight pass
+                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && (WPS <= 3 || (SPW == 1 && WPS == 5)));
                     f32x2 pkeep[KEEP ? SPW * NP : 1];
                     // A sample whose 16 rows have all converged leaves the loop on its own (wave-uniform masks on the scalar
                     // unit): with sparse supports the two samples of a group rarely finish in the same step.  Its tau, S and
@@ -911,26 +912,9 @@ static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, 
     return best;
 }
 
-// SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
-// nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
-template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
-static int launch_one(const FusedArgs& a, hipStream_t st) {
-#ifdef ARMNET_FORCE_SPW1                    // developer probe: one sample per wave-group everywhere (half-pad last tile)
-    constexpr int SPW = 1;
-#else
-    constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
-#endif
-    // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
-    // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
-    // generic-alpha Newton keeps two transcendental temporaries per pair alive)
-    constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
-                        : (E >= 32 || MODE == SOLVE_NEWTON || MODE == SOLVE_BISECT) ? 3      // measured: nemb=32 is faster at 3
-                        : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
-                        // alpha = 2, many fields: 3 waves/SIMD run as fast as 4 (measured with padded LDS: 92.7 vs 93.6 us)
-                        // and the 168-register budget holds the last evaluation's clamped differences, so the weight pass
-                        // does not recompute them: 88.1 -> 85.5 us.  Few fields (nfield = 10, 256 neurons): 4 is 7 % faster.
-                        : ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && SPW * NQ >= 16) ? 3
-                        : ARMNET_WPS;
+// One configuration (samples per wave-group, waves per SIMD) of a shape: sizes the block, launches the persistent grid.
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL>
+static int launch_cfg(const FusedArgs& a, hipStream_t st) {
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
     const size_t wave_bytes = (size_t)(NTILE * 16 * (E + 4) + 256) * sizeof(float);
@@ -976,6 +960,42 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     kern<<<(int)want, 64 * wpb, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
+}
+
+// SPW: two samples per wave-group when NQ % 4 != 0 (their 2*NQ quarter-steps fill whole tiles), one otherwise;
+// nemb = 64 always one sample (LDS / register budget; a half-pad last tile when NQ % 4 != 0)
+template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
+static int launch_one(const FusedArgs& a, hipStream_t st) {
+#ifdef ARMNET_FORCE_SPW1                    // developer probe: one sample per wave-group everywhere (half-pad last tile)
+    constexpr int SPW = 1;
+#else
+    constexpr int SPW = (E >= 64 || NQ % 4 == 0) ? 1 : 2;
+#endif
+    // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
+    // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
+    // generic-alpha Newton keeps two transcendental temporaries per pair alive)
+    constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
+                        : (E >= 32 || MODE == SOLVE_NEWTON || MODE == SOLVE_BISECT) ? 3      // measured: nemb=32 is faster at 3
+                        : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
+                        // alpha = 2, many fields: 3 waves/SIMD run as fast as 4 (measured with padded LDS: 92.7 vs 93.6 us)
+                        // and the 168-register budget holds the last evaluation's clamped differences, so the weight pass
+                        // does not recompute them: 88.1 -> 85.5 us.  Few fields (nfield = 10, 256 neurons): 4 is 7 % faster.
+                        : ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && SPW * NQ >= 16) ? 3
+                        : ARMNET_WPS;
+#ifndef ARMNET_NO_SPW1_W5
+    // Criteo-shaped blocks (33..40 fields, nemb <= 16, up to 32 neurons): ONE sample per wave-group at FIVE waves per SIMD
+    // (94-96 registers in every solver mode, no scratch).  The solver loop is wave-uniform — it runs until the slowest row
+    // of the group is done — and 16 rows instead of 32 need fewer evaluations (trained-like weights, alpha = 2: 4.9
+    // against 5.4 per pass); 20 smaller waves per CU overlap memory stalls and arithmetic at least as well as 12 larger
+    // ones, which pays for the half-padded third tile of MFMA #1 (12 instead of 10 MFMAs per sample and pass).
+    // Measured (bench.py, 1 x MI355X): random-init weights 87.4-87.6 us against 87.5-88.0; trained-like weights 116.8-117.0
+    // against 120.4-120.5; alpha = 1.7: 96.4-96.8 / 178.9-179.5 against 98.1-98.2 / 184.2-184.5; 64 / 128 neurons:
+    // +1.3 % on random-init weights, -0.4 / -2.3 % on trained-like ones: left on two-sample groups.
+    if constexpr (E == 16 && NQ == 10 && MODEL == MODEL_ARM && SPW == 2) {
+        if (a.O <= 32) return launch_cfg<E, NQ, 1, MODE, SRC, 5, MODEL>(a, st);
+    }
+#endif
+    return launch_cfg<E, NQ, SPW, MODE, SRC, WPS, MODEL>(a, st);
 }
 
 template <int E, int NQ, int SRC, int MODEL = MODEL_ARM>
