@@ -9,9 +9,11 @@ namespace armnet {
 static int mfma_cu_waves(int F, int E, int o_slice) {
     const int nq = (((F + 3) / 4) + 1) & ~1;
     const int ep = E <= 16 ? 16 : E <= 32 ? 32 : 64;
-    const int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
+    int spw = (ep >= 64 || nq % 4 == 0) ? 1 : 2;
+    int wps = ep >= 64 ? (nq >= 10 ? 2 : 3) : (ep >= 32 || spw * nq >= 16) ? 3 : 4;   // launch_one's register budget (alpha = 2)
+    const OccCfg oc = occ_config(ep, nq, SOLVE_MICHELOT);                              // ... or its high-occupancy table
+    if (oc.spw != 0 && (nq != 10 || o_slice <= 32)) { spw = oc.spw; wps = oc.wps; }
     const int ntile = (spw * nq + 3) / 4, nt = (o_slice + 15) / 16;
-    const int wps = ep >= 64 ? (nq >= 10 ? 2 : 3) : (ep >= 32 || spw * nq >= 16) ? 3 : 4;   // launch_one's register budget (alpha = 2)
     const size_t wave_bytes = (size_t)(ntile * 16 * (ep + 4) + 256) * sizeof(float);
     const size_t param_bytes = ((size_t)nt * (ep / 16) * 256 + (size_t)nt * (nq / 2) * 128 + (size_t)nt * 32) * sizeof(float);
     int b = 0;

@@ -161,6 +161,34 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 // (or 1 at 256 neurons, which is why such blocks used to be cut into slices that each re-gather the rows).
 constexpr int mfma_max_wpb(int wps) { return wps >= 3 ? 12 : 8; }
 
+// High-occupancy configurations (round 3).  The kernel overlaps two floors of similar height — the memory system's and
+// the SIMDs' issue time — and how well it does so is a matter of how many waves a SIMD can switch between: for the ARM
+// block the launcher therefore takes the LARGEST number of waves per SIMD whose register budget still holds the working
+// set without scratch (hipcc -S of every instantiation, tools/kernel_resources.py), with one-sample groups where that
+// halves the per-wave state.  {samples per wave-group, waves per SIMD}; {0, 0} = the two-sample / 3-4 wave defaults.
+struct OccCfg { int spw, wps; };
+constexpr OccCfg occ_config(int E, int NQ, int MODE) {
+#ifdef ARMNET_OCC_VARIANT                       // developer A/B: one wave per SIMD fewer than the table
+    constexpr int less = 1;
+#else
+    constexpr int less = 0;
+#endif
+    if (E == 16) {
+        return NQ == 2 ? OccCfg{2, 7 - less}          // 64-70 registers
+             : NQ == 4 ? OccCfg{1, 8 - less}          // 56-58
+             : NQ == 6 ? OccCfg{1, 6 - less}          // 72-76 (two-sample groups: 94 + scratch at 5 waves)
+             : NQ == 8 ? OccCfg{1, 6 - less}          // 78-80
+             : NQ == 10 ? OccCfg{1, 5}                // 94-96 (six waves spill: 119 us)
+             : NQ == 12 ? OccCfg{1, (MODE == SOLVE_BISECT ? 4 : 5) - less} : OccCfg{0, 0};
+    }
+    // nemb 17..32 was measured with the same rule (2-6 more waves per CU, one-sample groups for 17-32 fields) and is NOT in the
+    // table: alpha = 2 loses 1-10 % (22 fields, 32 / 128 neurons: 125.7 / 410.8 us against 120.3 / 393.3), only trained-like
+    // weights at alpha = 1.7 gain (up to 8 %): its 128-byte rows and 4-16 KiB of output per sample leave less to overlap.
+    return OccCfg{0, 0};
+}
+// ... and whether such a configuration also keeps the last evaluation's clamped differences (alpha = 2 / 1.5)
+constexpr bool occ_keeps(int E, int NQ, int SPW, int WPS) { return E == 16 && WPS >= 5 && occ_config(E, NQ, 0).spw == SPW; }
+
 template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM>
 __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
@@ -681,10 +709,10 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     // they converge.  When the loop ends every row's S was evaluated at its final threshold.
                     // generic alpha: p = t^r of the LAST evaluation is kept (the loop always ends on an evaluation
                     // at the final threshold), which saves the two transcendentals per element of a final pass
-                    // alpha = 2 with a 168-register budget (<= 3 waves/SIMD), or one-sample groups at 5 waves/SIMD (half the
-                    // pairs: 94 registers): the clamped differences of the last evaluation are kept as well, which saves
-                    // their recomputation in the weight pass
-                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && (WPS <= 3 || (SPW == 1 && WPS == 5)));
+                    // alpha = 2 with a 168-register budget (<= 3 waves/SIMD), or one of the high-occupancy configurations of
+                    // occ_config (few pairs per lane): the clamped differences of the last evaluation are kept as well,
+                    // which saves their recomputation in the weight pass
+                    constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && (WPS <= 3 || occ_keeps(E, NQ, SPW, WPS)));
                     f32x2 pkeep[KEEP ? SPW * NP : 1];
                     // A sample whose 16 rows have all converged leaves the loop on its own (wave-uniform masks on the scalar
                     // unit): with sparse supports the two samples of a group rarely finish in the same step.  Its tau, S and
@@ -982,20 +1010,30 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
                         // does not recompute them: 88.1 -> 85.5 us.  Few fields (nfield = 10, 256 neurons): 4 is 7 % faster.
                         : ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && SPW * NQ >= 16) ? 3
                         : ARMNET_WPS;
-#ifndef ARMNET_NO_SPW1_W5
-    // Criteo-shaped blocks (33..40 fields, nemb <= 16, up to 32 neurons): ONE sample per wave-group at FIVE waves per SIMD
-    // (94-96 registers in every solver mode, no scratch).  The solver loop is wave-uniform — it runs until the slowest row
-    // of the group is done — and 16 rows instead of 32 need fewer evaluations (trained-like weights, alpha = 2: 4.9
-    // against 5.4 per pass); 20 smaller waves per CU overlap memory stalls and arithmetic at least as well as 12 larger
-    // ones, which pays for the half-padded third tile of MFMA #1 (12 instead of 10 MFMAs per sample and pass).
-    // Measured (bench.py, 1 x MI355X): random-init weights 87.4-87.6 us against 87.5-88.0; trained-like weights 116.8-117.0
-    // against 120.4-120.5; alpha = 1.7: 96.4-96.8 / 178.9-179.5 against 98.1-98.2 / 184.2-184.5; 64 / 128 neurons:
-    // +1.3 % on random-init weights, -0.4 / -2.3 % on trained-like ones: left on two-sample groups.
-    if constexpr (E == 16 && NQ == 10 && MODEL == MODEL_ARM && SPW == 2) {
-        if (a.O <= 32) return launch_cfg<E, NQ, 1, MODE, SRC, 5, MODEL>(a, st);
+#ifndef ARMNET_NO_OCC_TABLE
+    // The ARM block at nemb <= 16 (every data set of the reference's run.sh: nemb = 10): the high-occupancy table above.
+    // Measured against the 3-4 wave configurations (kbench, 1 x MI355X, 32 neurons, random-init / trained-like weights at
+    // alpha = 2 / trained-like at alpha = 1.7): 3 fields -13 / -8 / -16 %, 10 fields -12 / -12 / -16 %, 22 fields -2 / -3 / -3 %,
+    // 30 fields -3 / -8 / -8 %, 43 fields -3 / -5 / -6 %; 128 neurons: -7..-15 %, -10..-15 %, 0..-3 %, -3..-8 %, -2..-3 %.
+    // Criteo-shaped blocks (33-40 fields; bench.py): random-init weights 87.4-87.6 us against 87.5-88.0, trained-like weights
+    // 116.8-117.0 against 120.4-120.5, alpha = 1.7 96.4-96.8 / 178.9-179.5 against 98.1-98.2 / 184.2-184.5 — the solver loop
+    // is wave-uniform and 16 rows need fewer evaluations than 32, twenty small waves per CU overlap better than twelve large
+    // ones, and that pays for the half-padded third tile of MFMA #1; at 64 / 128 neurons +1.3 % on random-init weights and
+    // -0.4 / -2.3 % on trained-like ones: those stay on two-sample groups.
+    if constexpr (MODEL == MODEL_ARM && occ_config(E, NQ, MODE).spw != 0) {
+        constexpr OccCfg oc = occ_config(E, NQ, MODE);
+        if constexpr (NQ != 10) {
+            return launch_cfg<E, NQ, oc.spw, MODE, SRC, oc.wps, MODEL>(a, st);
+        } else {
+            if (a.O <= 32) return launch_cfg<E, NQ, oc.spw, MODE, SRC, oc.wps, MODEL>(a, st);
+            return launch_cfg<E, NQ, SPW, MODE, SRC, WPS, MODEL>(a, st);
+        }
+    } else {
+        return launch_cfg<E, NQ, SPW, MODE, SRC, WPS, MODEL>(a, st);
     }
-#endif
+#else
     return launch_cfg<E, NQ, SPW, MODE, SRC, WPS, MODEL>(a, st);
+#endif
 }
 
 template <int E, int NQ, int SRC, int MODEL = MODEL_ARM>
