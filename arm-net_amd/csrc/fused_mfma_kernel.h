@@ -155,11 +155,13 @@ __device__ __forceinline__ float cmax2(float a, float b) { return __builtin_fmax
 //   MODEL_AFN     the tile holds log2(x); no MFMA #1 and no sparse map: the B operand of MFMA #2 is afn.weight with the
 //                 emb_bn scale folded in, the emb_bn shift goes into the bias (afn.py:63-66).
 //
-// Waves per block (blockDim.x / 64: 4, 8 or 12) is a LAUNCH parameter: the waves never talk to each other, they only
+// Waves per block (blockDim.x / 64: 4, 8, 12 or 16) is a LAUNCH parameter: the waves never talk to each other, they only
 // share the block's parameter copies in LDS.  Few neurons: 4 (several blocks per CU).  Many neurons (>= 128): the
 // parameter copies dominate the LDS, so ONE block of 12 waves per CU keeps 3 waves/SIMD where blocks of 4 would leave 2
 // (or 1 at 256 neurons, which is why such blocks used to be cut into slices that each re-gather the rows).
-constexpr int mfma_max_wpb(int wps) { return wps >= 3 ? 12 : 8; }
+// (round 3: 16 where the register budget allows 4+ waves per SIMD — 43 fields, 256 neurons: 636 -> 599 us, trained-like
+// weights 859 -> 795; nothing changes where 12 waves already fit beside the parameter copies.)
+constexpr int mfma_max_wpb(int wps) { return wps >= 4 ? 16 : wps >= 3 ? 12 : 8; }
 
 // High-occupancy configurations (round 3).  The kernel overlaps two floors of similar height — the memory system's and
 // the SIMDs' issue time — and how well it does so is a matter of how many waves a SIMD can switch between: for the ARM
@@ -924,7 +926,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
 #define ARMNET_WPS 4
 #endif
 
-// Waves per block for a block whose waves need `wave_bytes` of LDS each and share `param_bytes`: the choice (4, 8, 12;
+// Waves per block for a block whose waves need `wave_bytes` of LDS each and share `param_bytes`: the choice (4, 8, 12, 16;
 // at most mfma_max_wpb(wps)) that puts the most waves on a CU — blocks per CU bounded by the LDS and by wps waves per
 // SIMD —, the smaller block on a tie.  Returns 0 when not even 4 waves fit; *blocks_per_cu for the persistent grid.
 static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, int* blocks_per_cu) {
