@@ -317,12 +317,32 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     auto lane_off = [&](int n, bool short_grp) -> uint32_t {
         return (short_grp && off4[n] >= F4) ? off4[n] - F4 : off4[n];
     };
+    // One-sample groups fetch the sample's ids and values with ONE coalesced load each (lane f holds field f) and hand
+    // them to the four staging lanes of every row through ds_bpermute (cross-lane, no LDS memory): 3 + 2 vector-memory
+    // instructions per group instead of 3 + 3 + 3, in a kernel whose waves queue at vector-memory issue.
+#ifdef ARMNET_NO_COALESCED_IO
+    constexpr bool CO = false;
+#else
+    constexpr bool CO = (SPW == 1 && !FROM_ROWS);
+#endif
+    const uint32_t co_off = 4u * (uint32_t)(lane < F ? lane : F - 1);
     auto fetch_raw = [&](int gidx) {
         if constexpr (!FROM_ROWS) {
             const int gc = gidx < ngroups ? gidx : ngroups - 1;
             const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
             const bool short_grp = gc * SPW + SPW > Bi;              // wave-uniform, true at most once
             const char* ids_g = reinterpret_cast<const char*>(a.ids) + (size_t)e0 * (SRC == 0 ? 8 : 4);
+            if constexpr (CO) {
+                if constexpr (SRC == 0) {
+                    const u32x2 w = stream_load(reinterpret_cast<const u32x2*>(ids_g + (co_off << 1)));
+                    raw_lo[0] = w[0];
+                    raw_hi[0] = w[1];
+                } else {
+                    raw_lo[0] = stream_load(reinterpret_cast<const uint32_t*>(ids_g + co_off));
+                    raw_hi[0] = 0u;
+                }
+                return;
+            }
             auto body = [&](auto is_short) {                         // two copies: the common one has no per-lane select
 #pragma unroll
                 for (int n = 0; n < NI; ++n) {
@@ -346,6 +366,17 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         const uint32_t e0 = (uint32_t)(gc * SPW) * (uint32_t)F;
         const bool short_grp = gc * SPW + SPW > Bi;
         const char* vals_g = reinterpret_cast<const char*>(a.vals) + (size_t)e0 * 4;
+        if constexpr (CO) {
+            if (check_ids && (raw_hi[0] != 0u || raw_lo[0] > id_max)) atomicOr(a.id_status, 1);   // lanes >= F repeat field F-1
+            val_cur[0] = stream_load(reinterpret_cast<const float*>(vals_g + co_off));   // distributed at staging time
+            const int idc = (int)(min(raw_lo[0], id_max) & id_mask);                   // memory-safe even when unchecked
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute((int)off4[n], idc);      // off4 = 4 * field = its lane's byte address
+                rows_cur[n] = *reinterpret_cast<const RowTU*>(row_base + (size_t)id * row_bytes);
+            }
+            return;
+        }
         if constexpr (!FROM_ROWS) {
             if (check_ids) {                                         // wave-uniform branch
                 bool bad = false;
@@ -447,6 +478,11 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
 #endif
         bool changed = false;
         float vcl[NI];
+        if constexpr (CO) {
+            const int vco = __builtin_bit_cast(int, val_cur[0]);
+#pragma unroll
+            for (int n = NI - 1; n >= 0; --n) val_cur[n] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)off4[n], vco));
+        }
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             // clamp (armnet_1h.py:81; NaN stays NaN), scale (layers.py:21)
