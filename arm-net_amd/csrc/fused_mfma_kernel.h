@@ -305,9 +305,9 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     const uint32_t F4 = 4u * (uint32_t)F;
 
     // ---- software pipeline -------------------------------------------------------------------------
-    // iteration k:  stage rows(k) -> LDS | range-check ids(k+1), issue row + value loads(k+1)
-    //               | issue RAW id loads(k+2) | compute(k).  Nothing loaded in an iteration is looked at
-    //               before the next one.  All per-group addressing is scalar base (SALU) + a per-lane
+    // iteration k:  stage rows(k) -> LDS | first pass of compute(k) | range-check ids(k+1), issue row + value
+    //               loads(k+1) | issue RAW id loads(k+2) | stores, further passes.  Nothing loaded in an iteration
+    //               is looked at before the next one.  All per-group addressing is scalar base (SALU) + a per-lane
     //               constant offset; groups past the end re-read the last group, and in a short last
     //               group the lanes of the missing sample re-read sample 0 (results never stored).
     RowT rows_cur[NI];
@@ -523,24 +523,31 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 if (vcl[n] != val_cur[n] && chunk == 0 && !pad[n] && idx < BF) a.vals[idx] = vcl[n];
             }
         }
-        // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----
 #ifdef ARMNET_PHASE_TIMING
         wave_lds_fence();
         PHASE(7);
-        if constexpr (!FROM_ROWS) {
+#endif
+        // ---- keep the memory pipeline full: rows of the next group, raw ids of the one after -----------------------
+        // (one-sample id-fed groups of up to 40 fields at nemb <= 16 do this behind their first pass instead: LATE below)
+        auto prefetch = [&]() {
+#ifdef ARMNET_PHASE_TIMING
+            if constexpr (!FROM_ROWS) {
 #pragma unroll
-            for (int n = 0; n < NI; ++n) asm volatile("" : "+v"(raw_lo[n]), "+v"(raw_hi[n]));        // the ids have landed
-        }
-        PHASE(8);
+                for (int n = 0; n < NI; ++n) asm volatile("" : "+v"(raw_lo[n]), "+v"(raw_hi[n]));        // the ids have landed
+            }
+            PHASE(8);
 #endif
-        issue_rows_vals(grp + nwaves);
+            issue_rows_vals(grp + nwaves);
 #ifdef ARMNET_PHASE_TIMING
-        PHASE(9);
+            PHASE(9);
 #endif
-        fetch_raw(grp + 2 * nwaves);
+            fetch_raw(grp + 2 * nwaves);
 #ifdef ARMNET_PHASE_TIMING
-        PHASE(10);
+            PHASE(10);
 #endif
+        };
+        constexpr bool LATE = (E == 16 && SPW == 1 && NQ <= 10 && !FROM_ROWS);
+        if constexpr (!LATE) prefetch();
         wave_lds_fence();
         PHASE(0);
 
@@ -894,6 +901,15 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     }
             }
             PHASE(4);
+            // LATE: the next group's loads are issued HERE — behind the first pass's arithmetic, in front of its stores — and
+            // not right after staging: the address computation needs the next group's ids, hipcc cannot count the
+            // (conditional) stores that were issued after those ids and guards their first use with vmcnt(0), i.e. with a
+            // drain of the PREVIOUS group's output stores.  Right after staging that drain was 12 % of a wave's time; one
+            // pass later the stores have long landed (random-init / trained-like weights -0.4 / -0.9 %, alpha = 1.7 -1.1 %).
+            // Only where the longer live ranges cost no scratch (two-sample groups, nemb 32 and 41+ fields spill with it).
+            if constexpr (LATE) {
+                if (nt == 0) prefetch();
+            }
             // ---- epilogue: exp(z / S) = exp2(z * log2e / S) (rel. error <= ~|z| * 1.3e-7), BN affine, store
             const bool fast_store = full_rows && 16 * nt + 16 <= O;      // wave-uniform: whole 16-byte stores
             const bool o_ok = 16 * nt + c < O;
@@ -901,7 +917,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 const f32x2 bn0 = {bn[0], bn[0]}, bn1 = {bn[1], bn[1]};
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
-                    if (b0 + s < Bi) {
+                    if (SPW == 1 || b0 + s < Bi) {      // (a one-sample group inside the loop is always a real sample)
                         // wave-uniform part of the address on the scalar unit, the lane's part (c, g) a constant offset:
                         // mixed in one expression the 64-bit multiply ran on the VALU (two quarter-rate v_mul_lo_u32 and
                         // a v_mad_u64_u32 per sample and pass)
