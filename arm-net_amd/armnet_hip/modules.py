@@ -367,6 +367,20 @@ class ArmNetBase(nn.Module):
         if getattr(self, "_shard", None) is not None and getattr(self, "_shard_src", None) is not None:
             self._shard_src = (0, -1)
 
+    def warm_caches(self, heads=True):
+        """Build every lazily produced parameter cache NOW, on the current stream: q_fold + the BatchNorm affine, the
+        re-cut of the local shard, and (heads) the MLPs' packed / folded weights.  Whoever then forks work onto other
+        streams (serving.InFlight) reads caches that already exist instead of racing with the stream that first needs
+        them (round-3 advisor finding: one hook instead of attribute probing)."""
+        with torch.no_grad():
+            at = self.attn_layer
+            bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
+            self._folded.get(self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), bw, at.query, self.arm_bn)
+            if getattr(self, "_shard", None) is not None:
+                self._refresh_shard()
+            if heads and not self.training:
+                _warm_heads(self)
+
     def train(self, mode=True):
         self.invalidate_folded()
         return super().train(mode)
@@ -665,3 +679,13 @@ class _MLP(nn.Module):
         for wt, b, relu in self._fold():
             x = torch._addmm_activation(b, x, wt) if relu else torch.addmm(b, x, wt)
         return x
+
+
+def _warm_heads(model):
+    """pack / fold the eval-mode weights of every prediction head of `model` on the current stream"""
+    for sub in model.modules():
+        if isinstance(sub, _MLP):
+            if sub.hip_head and sub._hip_plan() is not None:
+                sub._pack()
+            elif sub.fold_eval:
+                sub._fold()

@@ -29,22 +29,11 @@ class InFlight:
         return s
 
     def _warm(self):
-        """refresh the lazily built parameter caches (q_fold + BatchNorm affine, the MLPs' packed / folded weights) on the
-        CALLER's stream: they are produced by whichever stream first needs them and then read by every later submit on
-        other streams, so they must exist before the side streams fork off (advisor finding r2)"""
-        m = self.model
-        with torch.no_grad():
-            if hasattr(m, "_folded") and hasattr(m, "attn_layer") and hasattr(m, "_d_k"):
-                at = m.attn_layer
-                bw = at.bilinear_w.weight if hasattr(at.bilinear_w, "weight") else at.bilinear_w
-                m._folded.get(m.variant, m.nhead, m.nhid, m.nemb, m._d_k(), bw, at.query, m.arm_bn)
-            if self.call != "arm_block" and not m.training:
-                for sub in m.modules():
-                    if hasattr(sub, "_hip_plan") and hasattr(sub, "_pack"):
-                        if sub.hip_head and sub._hip_plan() is not None:
-                            sub._pack()
-                        elif sub.fold_eval:
-                            sub._fold()
+        """refresh the lazily built parameter caches (q_fold + BatchNorm affines, the sibling models' folds, the re-cut
+        shard, the MLPs' packed / folded weights) on the CALLER's stream: they are produced by whichever stream first
+        needs them and then read by every later submit on other streams, so they must exist before the side streams fork
+        off (advisor findings r2, r3: one model hook, `warm_caches`, covers ARM-Net, GC-ARM and AFN)"""
+        self.model.warm_caches(heads=self.call != "arm_block")
 
     def submit(self, ids, vals):
         """Enqueue one batch; returns a handle for result().  x['value'] semantics: vals is clamped in place.

@@ -138,14 +138,20 @@ class RowShardedTable:
         exchange are derived from.  They must be the SAME on every rank — different slot sizes or different collectives
         would mismatch or hang — so they are a function of one agreed number, never of the local batch: `slot_lookups`
         if the caller set it, else the MAX over the ranks of the first lookup's size (one tiny all-reduce + host read,
-        once).  Later batches may be smaller (a ragged last batch: more slack) or larger: a slot may then overflow,
-        which is flagged and repaired like any overflow, and the next poll() — whose all-reduce also carries the largest
-        step seen since the last one — raises the agreed size on every rank at once.  `slot_lookups = None` re-agrees
-        at the next lookup, which every rank must then do together."""
+        once).  Later batches may be smaller (a ragged last batch: more slack).  A LARGER step than the agreed one
+        (a small warm-up batch or a B = 1 request first, full batches afterwards) re-agrees on the spot, with the same
+        tiny all-reduce, before anything is sized from it: the slots then never start out too small for a step whose
+        size the host already knows (round-3 advisor finding: with the agreement frozen at the first step's size every
+        slot overflowed until somebody polled, and unverified callers read wrong rows in between).  Like every
+        collective of the step this assumes SPMD batches — the ranks grow their step at the same call; a rank whose
+        batches grow on its own must set `slot_lookups` itself (then it is never touched here, and a too-small slot is
+        flagged and repaired like any overflow; the next poll() also carries the largest step seen and raises the agreed
+        size on every rank at once).  `slot_lookups = None` re-agrees at the next lookup, which every rank must then
+        do together."""
         self._n_seen = max(getattr(self, "_n_seen", 0), int(n))
-        if self.slot_lookups is None:
+        if self.slot_lookups is None or (getattr(self, "_slot_auto", False) and int(n) > self.slot_lookups):
             self._slot_auto = True
-            m = max(int(n), 1)
+            m = max(int(n), int(self.slot_lookups or 0), 1)
             if dist.is_initialized() and self.world > 1:
                 dev = self._table_local.device
                 t = torch.tensor([m], dtype=torch.int64, device="cpu" if self._via_host or not dev.type == "cuda" else dev)

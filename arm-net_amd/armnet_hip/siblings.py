@@ -59,6 +59,16 @@ class SiblingBase(nn.Module):
             if isinstance(m, _MLP):
                 m.invalidate()
 
+    def warm_caches(self, heads=True):
+        """build the lazily produced folds (q fold, emb_bn / arm_bn / afn_bn affines, the heads' packed weights) on the
+        current stream — see ArmNetBase.warm_caches"""
+        from .modules import _warm_heads
+        with torch.no_grad():
+            if not self.training:
+                self._fold()
+                if heads:
+                    _warm_heads(self)
+
     def train(self, mode=True):
         self.invalidate_folded()
         return super().train(mode)
