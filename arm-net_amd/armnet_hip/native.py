@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
@@ -31,6 +31,7 @@ EXPORTS = (
     "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
+    "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed",
 )
 
 _lib = None
@@ -64,6 +65,7 @@ def load():
     lib.armnet_strerror.restype = ctypes.c_char_p
     lib.armnet_shard_route_ws_bytes.restype = ctypes.c_int64
     lib.armnet_shard_route_unique_ws_bytes.restype = ctypes.c_int64
+    lib.armnet_shard_route_fixed_ws_bytes.restype = ctypes.c_int64
     lib.armnet_last_hip_error.restype = ctypes.c_char_p
     lib.armnet_mlp_packed_bytes.restype = ctypes.c_int64
     if lib.armnet_abi_version() != ABI_VERSION:
@@ -423,6 +425,22 @@ def shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, ove
         check(load().armnet_shard_pad_route(ctypes.c_int64(n), int(R), ctypes.c_int64(cap), _ptr(counts),
                                             _ptr(send_local), _ptr(perm), _ptr(send_pad), _ptr(perm_pad),
                                             _ptr(overflow), _stream()))
+
+
+def shard_route_fixed_ws_bytes(R, nfeat, dedup):
+    return int(load().armnet_shard_route_fixed_ws_bytes(int(R), ctypes.c_int64(nfeat), int(bool(dedup))))
+
+
+def shard_route_fixed(n, ids, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, workspace=None, id_status=None):
+    """routing of the fixed-capacity protocol in one call: send_pad [R*cap], perm_pad [n], counts [R], overflow flag"""
+    _ids_ok(ids)
+    _i32_ok(send_pad=send_pad, perm_pad=perm_pad, counts=counts, overflow=overflow)
+    with _on(ids, send_pad, perm_pad, counts, overflow, workspace, id_status):
+        check(load().armnet_shard_route_fixed(
+            ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), ctypes.c_int64(cap),
+            int(bool(dedup)), _ptr(send_pad), _ptr(perm_pad), _ptr(counts), _ptr(overflow), _ptr(id_status),
+            _ptr(workspace), ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
+            _stream()))
 
 
 def shard_direct_perm(n, ids, R, nfeat, perm, id_status=None):

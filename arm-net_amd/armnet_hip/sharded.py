@@ -4,8 +4,8 @@ Rank r of R owns the table rows ``{i : i % R == r}`` (local index ``i // R``; th
 balances skewed ids).  One lookup of a rank's ``ids [B, F]``, default protocol ("fixed": no host synchronisation
 anywhere in the step):
 
-    route      armnet_shard_route_ids: counting sort of the B*F ids by owner          (HIP, this rank)
-    pad        armnet_shard_pad_route: R equal slots of `cap` indices (cap ~ 1.25 n/R) (HIP, this rank)
+    route      armnet_shard_route_fixed: every lookup (or every DISTINCT id) gets a position in   (HIP, this rank)
+               its owner's slot — R equal slots of `cap` indices (cap ~ 1.25 n/R) — directly
     exchange   all_to_all_single, EQUAL splits, of int32 local row indices              (RCCL over xGMI)
     gather     armnet_gather_scale_f32(vals=NULL): owner reads its rows                 (HIP, HBM-bound)
     exchange   all_to_all_single, EQUAL splits, of the rows (E*4 bytes per slot entry)  (RCCL over xGMI)
@@ -81,6 +81,25 @@ class HipShardOps:
         native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
         return send_pad, perm_pad
 
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None):
+        """-> send_pad [R*cap], perm_pad [n] (armnet_shard_route_fixed: routing of the fixed-capacity protocol in one call —
+        one kernel without de-duplication, byte-map mark + chunk scan + emit + one position gather with it; round 4:
+        91 us -> see DESIGN.md for 2.56 M lookups).  overflow (int32[1]) |= 1 if a slot is too small."""
+        n = ids_flat.numel()
+        dev = ids_flat.device
+        buf = torch.empty(R * cap + R, device=dev, dtype=torch.int32)      # counts right behind the slots: one fill for both
+        send_pad, counts = buf[:R * cap], buf[R * cap:]
+        perm_pad = torch.empty(n, device=dev, dtype=torch.int32)
+        ws = None
+        if dedup:
+            need = native.shard_route_fixed_ws_bytes(R, nfeat, True)
+            key = (dev, torch.cuda.current_stream(dev).cuda_stream, "fixed")
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = self._ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+        native.shard_route_fixed(n, ids_flat, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, ws, id_status)
+        return send_pad, perm_pad
+
     def direct_perm(self, ids_flat, R, nfeat, id_status=None):
         """-> perm [n] int32: address of every id's row in the all-gathered shards (armnet_shard_direct_perm)"""
         perm = torch.empty(ids_flat.numel(), device=ids_flat.device, dtype=torch.int32)
@@ -107,6 +126,7 @@ class RowShardedTable:
         self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces); dropped
                                   # whenever `table_local` is assigned (the property below)
         self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
+        self.fused_route = True   # fixed protocol: armnet_shard_route_fixed (False: route + pad_route, the round-3 kernels)
         self.slot_lookups = None  # lookups per step the slots of the fixed protocol are sized for; None: agreed over the
                                   # ranks (MAX) by the first lookup — see _agreed_lookups
         self.table_local = table_local
@@ -138,20 +158,26 @@ class RowShardedTable:
         exchange are derived from.  They must be the SAME on every rank — different slot sizes or different collectives
         would mismatch or hang — so they are a function of one agreed number, never of the local batch: `slot_lookups`
         if the caller set it, else the MAX over the ranks of the first lookup's size (one tiny all-reduce + host read,
-        once).  Later batches may be smaller (a ragged last batch: more slack).  A LARGER step than the agreed one
-        (a small warm-up batch or a B = 1 request first, full batches afterwards) re-agrees on the spot, with the same
-        tiny all-reduce, before anything is sized from it: the slots then never start out too small for a step whose
-        size the host already knows (round-3 advisor finding: with the agreement frozen at the first step's size every
-        slot overflowed until somebody polled, and unverified callers read wrong rows in between).  Like every
-        collective of the step this assumes SPMD batches — the ranks grow their step at the same call; a rank whose
-        batches grow on its own must set `slot_lookups` itself (then it is never touched here, and a too-small slot is
-        flagged and repaired like any overflow; the next poll() also carries the largest step seen and raises the agreed
-        size on every rank at once).  `slot_lookups = None` re-agrees at the next lookup, which every rank must then
-        do together."""
+        once).  Later batches may be smaller (a ragged last batch: more slack) or larger: a slot may then overflow,
+        which is flagged and repaired like any overflow, and the next poll() — whose all-reduce also carries the largest
+        step seen since the last one — raises the agreed size on every rank at once.  A rank cannot do better on its own:
+        it may be the only one whose batch grew (ragged batches), and any collective it started alone would hang the job.
+        So the contract for UNVERIFIED callers (verify=False: bench-style serving loops that poll rarely) is: warm up with
+        the largest batch, or set `slot_lookups`, or call poll() after the first step of a new size — a step larger
+        than the agreed size warns once (round-3 advisor finding: a small warm-up batch followed by full batches
+        overflowed every slot until somebody polled, silently).  `slot_lookups = None` re-agrees at the next lookup,
+        which every rank must then do together."""
         self._n_seen = max(getattr(self, "_n_seen", 0), int(n))
-        if self.slot_lookups is None or (getattr(self, "_slot_auto", False) and int(n) > self.slot_lookups):
+        if self.slot_lookups is not None and int(n) > self.slot_lookups and not getattr(self, "_warned_growth", False):
+            import warnings
+            self._warned_growth = True
+            warnings.warn(f"row-sharded lookup of {int(n)} ids exceeds the agreed step size {self.slot_lookups}: slots of the "
+                          "fixed-capacity exchange may overflow until the next poll() / overflowed(); unverified callers "
+                          "should warm up with their largest batch, set slot_lookups, or poll after the first large step",
+                          RuntimeWarning, stacklevel=3)
+        if self.slot_lookups is None:
             self._slot_auto = True
-            m = max(int(n), int(self.slot_lookups or 0), 1)
+            m = max(int(n), 1)
             if dist.is_initialized() and self.world > 1:
                 dev = self._table_local.device
                 t = torch.tensor([m], dtype=torch.int64, device="cpu" if self._via_host or not dev.type == "cuda" else dev)
@@ -227,15 +253,19 @@ class RowShardedTable:
             self.last_path = "whole_shards"
             return self._lookup_whole_shards(flat, id_status)
         self.last_path = "fixed"
-        if n == 0:                                     # an empty slice still takes part in the exchanges
-            counts = torch.zeros(R, device=dev, dtype=torch.int32)
-            send_local = torch.zeros(1, device=dev, dtype=torch.int32)
-            perm = torch.empty(0, device=dev, dtype=torch.int32)
-        elif id_status is not None:
-            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
+        if n > 0 and self.fused_route and hasattr(self.ops, "route_fixed"):
+            # the slots directly (round 4): no back-to-back layout in between, no separate pad pass
+            send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status)
         else:
-            counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
-        send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
+            if n == 0:                                     # an empty slice still takes part in the exchanges
+                counts = torch.zeros(R, device=dev, dtype=torch.int32)
+                send_local = torch.zeros(1, device=dev, dtype=torch.int32)
+                perm = torch.empty(0, device=dev, dtype=torch.int32)
+            elif id_status is not None:
+                counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
+            else:
+                counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
+            send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
         E = self.table_local.shape[1]
         if R == 1 and not dist.is_initialized():
             return self.ops.gather(send_pad, self.table_local), perm_pad

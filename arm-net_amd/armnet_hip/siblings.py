@@ -103,6 +103,11 @@ class SiblingBase(nn.Module):
     def _finish(self, block, ids, v, v_run):
         if v_run is not v:
             v.copy_(v_run)                                       # keep the visible clamp side effect
+        if self.ensemble:
+            from .modules import _fused_ensemble_tail
+            fused = _fused_ensemble_tail(self, block.view(block.shape[0], -1), ids, v)
+            if fused is not None:
+                return fused.squeeze(1)
         y = self.mlp(block.view(block.shape[0], -1))
         if self.ensemble:
             x_deep = self.deep_embedding({"id": ids, "value": v}, check_ids=False)   # ids validated by the fused call

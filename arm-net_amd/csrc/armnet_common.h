@@ -17,37 +17,6 @@ enum SolverMode : int {
     SOLVE_NEWTON15 = 4   // alpha == 1.5: Newton with p = t*t (no transcendental)
 };
 
-struct SparseMapCfg {
-    int mode;
-    int n_iter;          // bisection steps (SOLVE_BISECT)
-    int ensure_sum_one;
-    float am1;           // alpha - 1            (fp32, entmax.py:42)
-    float r;             // 1 / (alpha - 1)      (fp32, entmax.py:22)
-    float tau_hi_off;    // (1/d) ** (alpha - 1) (entmax.py:47), also the mean-start offset
-};
-
-// Host: choose the solver the way armnet_hip.h documents.
-inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_sum_one, uint32_t flags) {
-    SparseMapCfg c;
-    c.n_iter = n_iter;
-    c.ensure_sum_one = ensure_sum_one;
-    c.am1 = alpha - 1.0f;
-    c.r = 1.0f / c.am1;
-    c.tau_hi_off = powf((float)(1.0 / (double)d), c.am1);
-    if (alpha == 1.0f) {
-        c.mode = SOLVE_SOFTMAX;
-    } else if ((flags & ARMNET_F_FAITHFUL_BISECT) || alpha > 2.0f || alpha < 1.0f || n_iter < 24 || !ensure_sum_one) {
-        c.mode = SOLVE_BISECT;
-    } else if (alpha == 2.0f) {
-        c.mode = SOLVE_MICHELOT;
-    } else if (alpha == 1.5f) {
-        c.mode = SOLVE_NEWTON15;
-    } else {
-        c.mode = SOLVE_NEWTON;
-    }
-    return c;
-}
-
 constexpr int kNewtonMaxIter = 40;
 // Stop once sum(p) - 1 <= tol.  The row is renormalised by sum(p) afterwards (entmax.py:63-64), which cancels the
 // first-order effect of the threshold error: |dp_i| <= tol * |t_i - 1/k| for a support of k.  Measured on MI355X
@@ -64,6 +33,42 @@ constexpr float kNewtonTol = ARMNET_NEWTON_TOL;
 #define ARMNET_NEWTON_TAU_TOL 2e-7f
 #endif
 constexpr float kNewtonTauTol = ARMNET_NEWTON_TAU_TOL;
+
+struct SparseMapCfg {
+    int mode;
+    int n_iter;          // bisection steps (SOLVE_BISECT)
+    int ensure_sum_one;
+    float am1;           // alpha - 1            (fp32, entmax.py:42)
+    float r;             // 1 / (alpha - 1)      (fp32, entmax.py:22)
+    float tau_hi_off;    // (1/d) ** (alpha - 1) (entmax.py:47), also the mean-start offset
+    float tau_tol;       // SOLVE_NEWTON (matrix-core forward): a row is also done once its Newton step is below this
+};
+
+// Host: choose the solver the way armnet_hip.h documents.
+inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_sum_one, uint32_t flags) {
+    SparseMapCfg c;
+    c.n_iter = n_iter;
+    c.ensure_sum_one = ensure_sum_one;
+    c.am1 = alpha - 1.0f;
+    c.r = 1.0f / c.am1;
+    c.tau_hi_off = powf((float)(1.0 / (double)d), c.am1);
+    // the step bounds every |dp_i| by r |dtau| with r = 1 / (alpha - 1): 2e-7 keeps that at 3e-7 for alpha >= 1.7 (where the
+    // rule was measured); below, the tolerance shrinks with alpha - 1 so that the bound stays 3e-7 — alpha = 1.1 would
+    // otherwise allow 2e-6 per element, a fifth of the parity bar (round-3 advisor finding)
+    c.tau_tol = kNewtonTauTol * fminf(1.0f, c.am1 * (1.0f / 0.7f));
+    if (alpha == 1.0f) {
+        c.mode = SOLVE_SOFTMAX;
+    } else if ((flags & ARMNET_F_FAITHFUL_BISECT) || alpha > 2.0f || alpha < 1.0f || n_iter < 24 || !ensure_sum_one) {
+        c.mode = SOLVE_BISECT;
+    } else if (alpha == 2.0f) {
+        c.mode = SOLVE_MICHELOT;
+    } else if (alpha == 1.5f) {
+        c.mode = SOLVE_NEWTON15;
+    } else {
+        c.mode = SOLVE_NEWTON;
+    }
+    return c;
+}
 
 // compute units of the current device (256 on MI355X), cached per device; 256 if the query fails
 int device_cu_count();

@@ -3,9 +3,9 @@
 
 namespace armnet {
 
-// nemb 4..64 (any, odd too), nfield <= 48; any neuron count (slices)
+// nemb 4..128 (any, odd too; above 64: nfield <= 32), nfield <= 48; any neuron count (slices)
 bool fused_bwd_mfma_supports(int F, int E, int O) {
-    return !(E < 4 || E > 64 || O < 1 || F < 1 || F > 48);
+    return !(E < 4 || E > 128 || O < 1 || F < 1 || F > (E > 64 ? 32 : 48));
 }
 
 int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
@@ -14,7 +14,7 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
     // slices of 32 (nemb = 64: 16) neurons: each re-stages the rows and adds its part of dx to the table gradient
-    const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64);
+    const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : a.E <= 32 ? 32 : a.E <= 64 ? 64 : 128);
     for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
         s.O = a.O - o0 < slice ? a.O - o0 : slice;
@@ -29,7 +29,8 @@ int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t st) {
         int rc;
         if (a.E <= 16) rc = launch_bwd_mfma_e16(s, nq, st);
         else if (a.E <= 32) rc = launch_bwd_mfma_e32(s, nq, st);
-        else rc = launch_bwd_mfma_e64(s, nq, st);
+        else if (a.E <= 64) rc = launch_bwd_mfma_e64(s, nq, st);
+        else rc = launch_bwd_mfma_e128(s, nq, st);
         if (rc != ARMNET_OK) return rc;
     }
     return ARMNET_OK;

@@ -39,10 +39,13 @@ namespace armnet {
 #ifndef ARMNET_BWD_E64_PASSES
 #define ARMNET_BWD_E64_PASSES 2    // measured: 2 passes with ~128 B of scratch beat 1 pass without (1.42 vs 1.74 ms)
 #endif
-constexpr int bwd_passes(int E) { return E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : ARMNET_BWD_E16_PASSES; }
+// nemb 65..128 (round 4): 8 accumulator tiles per 16 neurons and per 16 tile rows — one pass per launch, one wave per SIMD
+// (the 512-register budget holds the dx tiles of up to 32 fields beside the staged rows and dz / z)
+constexpr int bwd_passes(int E) { return E >= 128 ? 1 : E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : ARMNET_BWD_E16_PASSES; }
+constexpr int bwd_blocks_per_cu(int E) { return E >= 128 ? 1 : ARMNET_BWD_BLOCKS_PER_CU; }
 
 template <int E, int NQ, int MODE, int SRC>
-__global__ void __launch_bounds__(256, ARMNET_BWD_BLOCKS_PER_CU) fused_bwd_mfma_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kernel(BwdArgs a) {
     constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
     constexpr int ROWS = NTILE * 16;
     constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
@@ -702,7 +705,7 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
 #endif
     int per_cu = (int)(160 * 1024 / lds);
-    if (per_cu > ARMNET_BWD_BLOCKS_PER_CU) per_cu = ARMNET_BWD_BLOCKS_PER_CU;
+    if (per_cu > bwd_blocks_per_cu(E)) per_cu = bwd_blocks_per_cu(E);
     const int64_t blocks = (a.B + 3) / 4;
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
@@ -732,5 +735,6 @@ static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
 int launch_bwd_mfma_e16(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e32(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e64(const BwdArgs& a, int nq, hipStream_t st);
+int launch_bwd_mfma_e128(const BwdArgs& a, int nq, hipStream_t st);    // nq 2..8 (wider samples do not fit the LDS)
 
 }  // namespace armnet

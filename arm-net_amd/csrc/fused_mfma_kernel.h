@@ -1,5 +1,5 @@
 // fused_mfma_kernel.h — the fused ARM block on the CDNA4 matrix cores (gfx950), fp32 end to end.
-// Template + launcher; instantiated per padded embedding width (16 / 32 / 64) in fused_mfma_e*.hip.
+// Template + launcher; instantiated per padded embedding width (16 / 32 / 64 / 128) in fused_mfma_e*.hip.
 //
 // Measured facts this kernel is built around (tools/ubench/valu_rate.hip, profiles/):
 //   * v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and its cycles ADD to the VALU cycles of
@@ -12,7 +12,7 @@
 //
 //   stage     coalesced 16-byte chunk loads (4-byte aligned: any nemb >= 4) of the F embedding rows of each sample
 //             (adjacent lanes share a row), scaled by clamp(value), written to the wave's LDS tile whose rows
-//             are zero-padded to E = 16/32/64 floats.  Rows of the NEXT group are already in flight
+//             are zero-padded to E = 16/32/64/128 floats.  Rows of the NEXT group are already in flight
 //             (registers) and the raw ids of the group after that are being fetched.
 //   per 16-neuron pass nt:
 //   MFMA #1   gates  G[(s,f), o] = X[(s,f), :] . q_fold[o, :]   (v_mfma_f32_16x16x4_f32, exact fp32).
@@ -30,7 +30,7 @@
 //   epilogue  1/sum(p) folded into the exponent scale, exp2, eval-BatchNorm affine, one 16-byte store per lane
 //             and 16 embedding dims (4-byte aligned; the partial last chunk of a row as 8 bytes or elements).
 //
-// Shapes: nemb 4..64, nfield <= 48, nhead*nhid <= 256 per launch (neurons padded to 16 per pass).
+// Shapes: nemb 4..128, nfield <= 48, nhead*nhid <= 256 per launch (neurons padded to 16 per pass).
 #pragma once
 #include <stdlib.h>
 
@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     const float rr = a.cfg.r, rm1 = a.cfg.r - 1.0f;
     const float invF = 1.0f / (float)F;
     const float tau_off = a.cfg.tau_hi_off;
+    const float tau_tol = a.cfg.tau_tol;                  // generic alpha: step tolerance, scaled by alpha - 1 below 1.7
     const float L2E = kLog2e;
 
     for (; grp < ngroups; grp += nwaves) {
@@ -833,7 +834,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                             // alpha = 2 / 1.5 have no transcendental noise, take one evaluation on dense rows anyway, and lose
                             // parity margin to the looser test (0.42 -> 0.54 / 0.22 -> 0.29): residual only.
                             float thr = kNewtonTol;
-                            if constexpr (MODE == SOLVE_NEWTON) thr = __builtin_fmaxf(thr, kNewtonTauTol * Dv);
+                            if constexpr (MODE == SOLVE_NEWTON) thr = __builtin_fmaxf(thr, tau_tol * Dv);
                             const bool c_f = f > thr, c_t = tn > tau[s];
                             const bool act = c_f && c_t && !dbg_no_solve;
                             tau[s] = act ? tn : tau[s];
@@ -1056,7 +1057,9 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
     // waves/SIMD the register allocator targets: 4 (128 VGPRs) where the working set fits without scratch
     // traffic in the solver loop, fewer for the wide shapes (nemb=64 is LDS-limited to 2 blocks/CU anyway;
     // generic-alpha Newton keeps two transcendental temporaries per pair alive)
-    constexpr int WPS = (E >= 64) ? (NQ >= 10 ? 2 : 3)
+    // nemb 65..128 (round 4): 8 accumulator tiles of MFMA #2 and up to 24 staging registers x 4 per wave
+    constexpr int WPS = (E >= 128) ? (NQ >= 6 ? 2 : 3)
+                        : (E >= 64) ? (NQ >= 10 ? 2 : 3)
                         : (E >= 32 || MODE == SOLVE_NEWTON || MODE == SOLVE_BISECT) ? 3      // measured: nemb=32 is faster at 3
                         : (MODE == SOLVE_SOFTMAX && SPW * NQ >= 20) ? 3
                         // alpha = 2, many fields: 3 waves/SIMD run as fast as 4 (measured with padded LDS: 92.7 vs 93.6 us)
@@ -1128,6 +1131,8 @@ static int launch_src(const FusedArgs& a, hipStream_t st) {
 int launch_mfma_e16(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e32(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e64(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e128a(const FusedArgs& a, int nq, hipStream_t st);    // nq 2..6
+int launch_mfma_e128b(const FusedArgs& a, int nq, hipStream_t st);    // nq 8..12
 int launch_gc_e16(const FusedArgs& a, int nq, hipStream_t st);
 int launch_gc_e32(const FusedArgs& a, int nq, hipStream_t st);
 int launch_gc_e64(const FusedArgs& a, int nq, hipStream_t st);

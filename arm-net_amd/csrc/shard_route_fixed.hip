@@ -1,0 +1,346 @@
+// shard_route_fixed.hip — routing of the row-sharded lookup's FIXED-capacity protocol in one entry point (SURVEY.md §8e;
+// no reference counterpart).  Round 3 ran the request-list step as route (counting sort, or direct-address mark + hipCUB
+// scan + compact + perm) followed by a separate pad pass: 91 us per 2.56 M lookups on one MI355X, more than the fused
+// block it feeds.  The slots of the fixed protocol make most of that unnecessary: an owner's slot is `cap` entries wide
+// whatever the data looks like, so a lookup only needs a UNIQUE position inside its owner's slot — not a sorted one — and
+// the padded layout can be written directly.
+//
+//   armnet_shard_route_fixed(n, ids, R, nfeat, cap, dedup, ...) ->
+//       send_pad[o*cap + s]  local row index (id / R) of the s-th request to owner o (= id % R); unused entries 0
+//       perm_pad[i]          o*cap + s of lookup i (index of its row in the buffer the row exchange returns)
+//       counts[o]            requests to owner o (may exceed cap: *overflow |= 1, surplus lookups point at slot 0)
+//
+// dedup = 0 — every lookup is a request.  ONE kernel: a block takes 2048 lookups, ranks them per owner with LDS
+//   atomics, reserves its share of each owner's slot with one global atomicAdd per owner, writes both arrays.
+//   Positions inside a slot depend on the order in which blocks reserve (run to run), the rows fetched do not.
+// dedup = 1 — every DISTINCT id is a request (2.56 M uniform lookups of 1 M rows ask for 0.92 M rows).  Direct-address
+//   BYTE map over (owner, local) — measured (tools/ubench/route_mark.hip): 2.56 M byte stores into a 1 MB map 14 us,
+//   4-byte stores 32 us, atomicOr into a bitmap 98-124 us — then chunk sums, a one-block scan with a restart at every
+//   owner, and an emit pass that writes the slots and a position table pos[p]; perm_pad[i] = pos[p(id_i)] is the one
+//   gather left (4-byte reads from a table that fits the L2).  Requests inside a slot come out sorted by local row
+//   index (the owner-side gather walks its shard monotonically).
+#include "armnet_common.h"
+
+namespace armnet {
+
+constexpr int RF_TPB = 256;
+constexpr int RF_PER = 8;                     // lookups per thread (dedup = 0)
+constexpr int RF_MAX_R = 64;
+constexpr int RF_CHUNK = 1024;                // bytes of the mark map per block (dedup = 1): 4 per thread (one 32-bit load)
+
+// id -> (owner, local) with a shift when R is a power of two (the usual 2, 4, 8 ranks)
+struct OwnerMap {
+    uint32_t R;
+    int shift;                                // log2(R), or -1
+    __device__ __forceinline__ void split(uint32_t id, uint32_t& owner, uint32_t& local) const {
+        if (shift >= 0) {
+            owner = id & (R - 1u);
+            local = id >> shift;
+        } else {
+            local = id / R;
+            owner = id - local * R;
+        }
+    }
+};
+static OwnerMap make_owner_map(int R) {
+    OwnerMap m;
+    m.R = (uint32_t)R;
+    m.shift = -1;
+    for (int s = 0; s < 31; ++s)
+        if ((1 << s) == R) m.shift = s;
+    return m;
+}
+
+template <typename IdT>
+__device__ __forceinline__ uint32_t checked_id(const IdT* ids, int64_t i, int64_t nfeat, int32_t* id_status) {
+    const uint64_t v = (uint64_t)(int64_t)ids[i];
+    const bool bad = v >= (uint64_t)nfeat;
+    if (bad && id_status) atomicOr(id_status, 1);
+    return bad ? 0u : (uint32_t)v;
+}
+
+// ---- dedup = 0 ------------------------------------------------------------------------------------------------------------
+template <typename IdT>
+__global__ void __launch_bounds__(RF_TPB)
+route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t cap,
+                   int32_t* __restrict__ send_pad, int32_t* __restrict__ perm_pad, int32_t* __restrict__ counts,
+                   int32_t* overflow, int32_t* id_status) {
+    __shared__ int hist[RF_MAX_R];
+    __shared__ int base[RF_MAX_R];
+    const int R = (int)om.R;
+    if ((int)threadIdx.x < R) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * (RF_TPB * RF_PER) + threadIdx.x;
+    uint32_t owner[RF_PER], local[RF_PER];
+    int rank[RF_PER];
+#pragma unroll
+    for (int k = 0; k < RF_PER; ++k) {
+        const int64_t i = i0 + (int64_t)k * RF_TPB;
+        if (i < n) {
+            om.split(checked_id(ids, i, nfeat, id_status), owner[k], local[k]);
+            rank[k] = atomicAdd(&hist[owner[k]], 1);               // LDS: unique rank of this lookup among the block's requests to that owner
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < R) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]) : 0;
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < RF_PER; ++k) {
+        const int64_t i = i0 + (int64_t)k * RF_TPB;
+        if (i < n) {
+            const int64_t s = (int64_t)base[owner[k]] + rank[k];
+            const int64_t slot0 = (int64_t)owner[k] * cap;
+            if (s < cap) {
+                send_pad[slot0 + s] = (int32_t)local[k];
+                perm_pad[i] = (int32_t)(slot0 + s);
+            } else {
+                perm_pad[i] = (int32_t)slot0;                      // a valid row, the wrong one: the step is repeated exactly
+                over = true;
+            }
+        }
+    }
+    if (over) atomicOr(overflow, 1);
+}
+
+// ---- dedup = 1 ------------------------------------------------------------------------------------------------------------
+// position of an id in the (owner, local) order, owners padded to Lp (a multiple of RF_CHUNK) entries
+template <typename IdT>
+__global__ void __launch_bounds__(RF_TPB)
+uniq_mark_bytes_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+                       unsigned char* __restrict__ mark, int32_t* id_status) {
+    for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
+        uint32_t o, l;
+        om.split(checked_id(ids, i, nfeat, id_status), o, l);
+        mark[(int64_t)o * Lp + l] = 1;
+    }
+}
+
+__device__ __forceinline__ int nonzero_bytes(uint32_t w) {
+    // one bit per non-zero byte (the map only ever holds 0 / 1)
+    return __popc(w & 0x01010101u);
+}
+
+__global__ void __launch_bounds__(RF_TPB)
+uniq_chunk_sums_kernel(const unsigned char* __restrict__ mark, int* __restrict__ sums) {
+    __shared__ int wsum[RF_TPB / 64];
+    const uint32_t v = reinterpret_cast<const uint32_t*>(mark + (size_t)blockIdx.x * RF_CHUNK)[threadIdx.x];
+    int c = nonzero_bytes(v);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one block: exclusive scan of the chunk sums that restarts at every owner (cpo chunks per owner); counts, overflow
+__global__ void __launch_bounds__(1024)
+uniq_scan_kernel(int nchunk, int cpo, int R, int64_t cap, const int* __restrict__ sums, int* __restrict__ base,
+                 int32_t* __restrict__ counts, int32_t* overflow) {
+    __shared__ int part[1024];
+    // thread t scans a contiguous run of chunks; runs never straddle an owner when cpo % per == 0 is not guaranteed, so the
+    // scan carries (value, owner of the run's first chunk) explicitly: simple two-level scheme per owner instead
+    for (int o = 0; o < R; ++o) {
+        const int c0 = o * cpo;
+        const int per = (cpo + 1023) / 1024;
+        const int lo = c0 + (int)threadIdx.x * per;
+        const int hi = min(lo + per, c0 + cpo);
+        int acc = 0;
+        for (int c = lo; c < hi; ++c) acc += sums[c];
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                        // Hillis-Steele inclusive scan over the 1024 partials
+            const int v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int run = part[threadIdx.x] - acc;                          // exclusive prefix of this thread's run
+        for (int c = lo; c < hi; ++c) {
+            base[c] = run;
+            run += sums[c];
+        }
+        if (threadIdx.x == 1023) {
+            counts[o] = part[1023];
+            if (part[1023] > cap) atomicOr(overflow, 1);
+        }
+        __syncthreads();
+    }
+    (void)nchunk;
+}
+
+// slots + position table; the blocks of an owner share the zero fill of its slot's unused tail.
+// SCAN_HERE: the block sums the chunk sums of its owner itself (the ones in front of it: its base; all of them: the
+// owner's count) instead of reading a scanned array — one launch and 10 R block-wide barriers of a single block less;
+// cpo loads per block, so only while an owner has few chunks (launcher: cpo <= 8192).
+template <bool SCAN_HERE>
+__global__ void __launch_bounds__(RF_TPB)
+uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restrict__ mark, const int* __restrict__ base,
+                 int32_t* __restrict__ counts, int32_t* __restrict__ send_pad, int32_t* __restrict__ pos, int32_t* overflow) {
+    __shared__ int wsum[RF_TPB / 64];
+    __shared__ int bsum[2][RF_TPB / 64];
+    const int chunk = blockIdx.x, o = chunk / cpo, j = chunk - o * cpo;
+    int my_base, my_count;
+    if constexpr (SCAN_HERE) {
+        const int* sums = base;                                     // un-scanned chunk sums
+        int before = 0, all = 0;
+        for (int c = threadIdx.x; c < cpo; c += RF_TPB) {
+            const int v = sums[o * cpo + c];
+            all += v;
+            before += c < j ? v : 0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d);
+            all += __shfl_xor(all, d);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            bsum[0][threadIdx.x >> 6] = before;
+            bsum[1][threadIdx.x >> 6] = all;
+        }
+        __syncthreads();
+        my_base = bsum[0][0] + bsum[0][1] + bsum[0][2] + bsum[0][3];
+        my_count = bsum[1][0] + bsum[1][1] + bsum[1][2] + bsum[1][3];
+        if (j == 0 && threadIdx.x == 0) {
+            counts[o] = my_count;
+            if (my_count > cap) atomicOr(overflow, 1);
+        }
+    } else {
+        my_base = base[chunk];
+        my_count = counts[o];
+    }
+    // a thread owns 4 consecutive positions (one 32-bit word of the map): the position table is written as ONE 16-byte store
+    // per lane, contiguous over the wave; the slot entries of consecutive set bytes are consecutive too
+    const int64_t p0 = (int64_t)chunk * RF_CHUNK + (int64_t)threadIdx.x * 4;
+    const uint32_t w = reinterpret_cast<const uint32_t*>(mark + (size_t)chunk * RF_CHUNK)[threadIdx.x];
+    const int mine = nonzero_bytes(w);
+    int incl = mine;                                                // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int s = my_base + incl - mine;
+    for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) s += wsum[q];
+    const int64_t slot0 = (int64_t)o * cap;
+    const int64_t l0 = p0 - (int64_t)o * Lp;                        // local row index of this thread's first byte
+    int4 pv;
+    int* pvp = reinterpret_cast<int*>(&pv);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const bool set = (w >> (8 * b)) & 1u;
+        const bool fits = s < cap;
+        if (set && fits) send_pad[slot0 + s] = (int32_t)(l0 + b);
+        pvp[b] = (int32_t)(slot0 + (fits ? s : 0));                 // (unset positions: never read)
+        s += set ? 1 : 0;
+    }
+    *reinterpret_cast<int4*>(pos + p0) = pv;
+    // unused tail of the owner's slot: a valid row index (0), fetched and never looked at
+    const int64_t used = my_count < cap ? my_count : cap;
+    const int64_t tail = cap - used, per = (tail + cpo - 1) / cpo;
+    const int64_t t0 = used + (int64_t)j * per, t1 = t0 + per < cap ? t0 + per : cap;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += RF_TPB) send_pad[slot0 + t] = 0;
+}
+
+template <typename IdT>
+__global__ void __launch_bounds__(RF_TPB)
+uniq_perm_pad_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+                     const int32_t* __restrict__ pos, int32_t* __restrict__ perm_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
+        const uint64_t v = (uint64_t)(int64_t)ids[i];
+        uint32_t o, l;
+        om.split(v >= (uint64_t)nfeat ? 0u : (uint32_t)v, o, l);
+        perm_pad[i] = pos[(int64_t)o * Lp + l];
+    }
+}
+
+static int64_t rf_Lp(int R, int64_t nfeat) {
+    const int64_t L = (nfeat + R - 1) / R;
+    return (L + RF_CHUNK - 1) / RF_CHUNK * RF_CHUNK;
+}
+
+size_t shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
+    if (!dedup) return 16;
+    const int64_t P = (int64_t)R * rf_Lp(R, nfeat), nchunk = P / RF_CHUNK;
+    return (size_t)P /* mark */ + (size_t)P * 4 /* pos */ + (size_t)nchunk * 8 /* sums, base */ + 256;
+}
+
+int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
+                             int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow, int32_t* id_status,
+                             void* ws, size_t ws_bytes, hipStream_t st) {
+    if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if ((int64_t)R * cap >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) || nfeat >= ((int64_t)1 << 32)) return ARMNET_ERR_UNSUPPORTED;
+    const OwnerMap om = make_owner_map(R);
+    if (!dedup) {
+        // unused slot entries: row 0; the reservation counters start at 0.  One fill when the caller put counts right behind
+        // send_pad (armnet_hip/sharded.py does): a fill of 32 bytes costs a launch like one of 13 MB
+        if (counts == send_pad + (size_t)R * cap) {
+            ARMNET_HIP_TRY(hipMemsetAsync(send_pad, 0, sizeof(int32_t) * ((size_t)R * cap + R), st));
+        } else {
+            ARMNET_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * R, st));
+            ARMNET_HIP_TRY(hipMemsetAsync(send_pad, 0, sizeof(int32_t) * (size_t)R * cap, st));
+        }
+        if (n == 0) return ARMNET_OK;
+        const int64_t grid = (n + RF_TPB * RF_PER - 1) / (RF_TPB * RF_PER);
+        if (id_type == ARMNET_ID_I64)
+            route_slots_kernel<int64_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, cap, send_pad, perm_pad, counts, overflow, id_status);
+        else
+            route_slots_kernel<int32_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, cap, send_pad, perm_pad, counts, overflow, id_status);
+        ARMNET_LAUNCH_CHECK();
+        return ARMNET_OK;
+    }
+    const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp, nchunk = P / RF_CHUNK;
+    if (P >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
+    if (n == 0) ARMNET_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * R, st));   // (otherwise the emit pass writes every count)
+    unsigned char* mark = reinterpret_cast<unsigned char*>(ws);
+    int32_t* pos = reinterpret_cast<int32_t*>(mark + P);
+    int* sums = reinterpret_cast<int*>(pos + P);
+    int* base = sums + nchunk;
+    ARMNET_HIP_TRY(hipMemsetAsync(mark, 0, (size_t)P, st));
+    const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
+    if (n > 0) {
+        if (id_type == ARMNET_ID_I64) uniq_mark_bytes_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, mark, id_status);
+        else uniq_mark_bytes_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, mark, id_status);
+        ARMNET_LAUNCH_CHECK();
+    }
+    uniq_chunk_sums_kernel<<<(int)nchunk, RF_TPB, 0, st>>>(mark, sums);
+    ARMNET_LAUNCH_CHECK();
+    const int cpo = (int)(Lp / RF_CHUNK);
+    if (cpo <= 8192) {
+        uniq_emit_kernel<true><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, sums, counts, send_pad, pos, overflow);
+    } else {
+        uniq_scan_kernel<<<1, 1024, 0, st>>>((int)nchunk, cpo, R, cap, sums, base, counts, overflow);
+        ARMNET_LAUNCH_CHECK();
+        uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, base, counts, send_pad, pos, overflow);
+    }
+    ARMNET_LAUNCH_CHECK();
+    if (n > 0) {
+        if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, pos, perm_pad);
+        else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, pos, perm_pad);
+        ARMNET_LAUNCH_CHECK();
+    }
+    return ARMNET_OK;
+}
+
+}  // namespace armnet
+
+using namespace armnet;
+
+extern "C" int64_t armnet_shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
+    if (R < 1 || nfeat <= 0) return -1;
+    return (int64_t)shard_route_fixed_ws_bytes(R, nfeat, dedup);
+}
+
+extern "C" int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap,
+                                        int dedup, int32_t* send_pad, int32_t* perm_pad, int32_t* counts,
+                                        int32_t* overflow, int32_t* id_status, void* workspace, int64_t ws_bytes,
+                                        void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || cap < 1 || !send_pad || !counts || !overflow || (n > 0 && (!ids || !perm_pad)))
+        return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
+                                    workspace, (size_t)ws_bytes, (hipStream_t)stream);
+}

@@ -120,6 +120,7 @@ def build_model(a, device, rank=0, world=1, regime=None):
         m._shard = RowShardedTable(shard, a.nfeat, None, protocol=a.protocol,
                                    dedup={"auto": "auto", "on": True, "off": False}[a.dedup])
         m._shard.micro_batches = a.micro_batches
+        m._shard.whole_shard = "auto" if getattr(a, "whole_shard", "auto") == "auto" else False
         m.nfeat = a.nfeat
     return m
 

@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: round-2 additions (prediction head, GC-ARM / AFN entry points, fixed-capacity and whole-shard routing helpers);
  * everything of version 1 is unchanged */
-#define ARMNET_ABI_VERSION 2
+#define ARMNET_ABI_VERSION 3
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
@@ -241,6 +241,23 @@ int armnet_shard_route_unique_ids(int64_t n, const void* ids, int id_type, int R
  */
 int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts, const int32_t* send_local,
                            const int32_t* perm, int32_t* send_pad, int32_t* perm_pad, int32_t* overflow, void* stream);
+
+/*
+ * Routing of the fixed-capacity protocol in ONE call (csrc/shard_route_fixed.hip; round 4): what armnet_shard_route_ids /
+ * _unique_ids followed by armnet_shard_pad_route produce, without the intermediate back-to-back layout — a lookup only
+ * needs a unique position inside its owner's slot.  send_pad [R*cap]: local row indices (id / R) requested from owner
+ * o = id % R in entries [o*cap, o*cap + min(counts[o], cap)), index 0 in the rest; perm_pad [n]: o*cap + s of lookup i;
+ * counts [R]; *overflow |= 1 when counts[o] > cap (the surplus lookups point at entry o*cap: the caller repeats the step
+ * with the exact protocol).  dedup != 0: every DISTINCT id is requested once (byte map over (owner, local) + chunk scan;
+ * requests sorted by local index inside a slot; workspace armnet_shard_route_fixed_ws_bytes(R, nfeat, 1) bytes).
+ * dedup == 0: every lookup is a request; slot positions are reserved with atomics, so send_pad / perm_pad may differ
+ * from run to run — send_pad[perm_pad[i]] == id_i / R always holds; no workspace.  *id_status |= 1 for an id outside
+ * [0, nfeat) (it reads row 0).  No reference counterpart (the reference is single-device).
+ */
+int64_t armnet_shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup);
+int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
+                             int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
+                             int32_t* id_status, void* workspace, int64_t ws_bytes, void* stream);
 
 /*
  * Whole-shard exchange of the row-sharded lookup (csrc/shard_pad.hip): when a batch asks for most of every shard the

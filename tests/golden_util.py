@@ -13,7 +13,7 @@ def model_cases():
 
 
 def grad_cases():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "h[123]_grad_*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "h[1234]_grad_*.npz")))
 
 
 def load(name):

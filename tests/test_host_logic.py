@@ -73,7 +73,11 @@ def test_kernel_selection_covers_the_reference_run_sh_shapes():
     assert k(39, 10, 128, 2.0, n_iter=10) == 1
     assert k(39, 10, 128, 2.0, flags=native.F_FAITHFUL_BISECT) == 1
     assert k(39, 10, 128, 2.0, flags=native.F_FORCE_GENERIC) == 0
-    assert k(39, 11, 128, 2.0) == 1 and k(39, 3, 128, 2.0) == 0 and k(39, 2, 128, 2.0) == 0 and k(39, 128, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
+    assert k(39, 11, 128, 2.0) == 1 and k(39, 3, 128, 2.0) == 0 and k(39, 2, 128, 2.0) == 0 and k(39, 129, 32, 2.0) == 0 and k(64, 16, 32, 2.0) == 0 and k(39, 16, 2048, 2.0) == 0
+    # round 4: nemb 65..128 on the matrix cores — the reference's own best-AUC command is Frappe --nemb 100 --h 10 --alpha 1.7
+    # (README.md:32-42)
+    for F, E, O in [(10, 100, 10), (39, 96, 32), (22, 72, 32), (39, 128, 256), (10, 120, 10), (48, 128, 1024), (39, 65, 128)]:
+        assert k(F, E, O, 1.7) == 1 and k(F, E, O, 2.0) == 1 and k(F, E, O, 2.5) == 1 and k(F, E, O, 1.0) == 1, (F, E, O)
     with pytest.raises(native.ArmnetNativeError):
         k(0, 16, 32, 2.0)
 

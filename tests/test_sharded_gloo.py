@@ -44,6 +44,28 @@ class NumpyShardOps:
         L = (nfeat + R - 1) // R
         return torch.from_numpy(((ids % R) * L + ids // R).astype(np.int32))
 
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None):
+        """contract of armnet_shard_route_fixed: the slots directly; positions inside a slot are ANY unique assignment
+        (here: reversed arrival order without de-duplication, sorted by local index with it)"""
+        ids = ids_flat.numpy().astype(np.int64)
+        owner, local = ids % R, ids // R
+        send_pad = np.zeros(R * cap, np.int32)
+        perm_pad = np.empty(ids.size, np.int32)
+        for o in range(R):
+            sel = np.nonzero(owner == o)[0]
+            if dedup:
+                u, inv = np.unique(local[sel], return_inverse=True)
+                slot = inv
+            else:
+                u = local[sel][::-1]
+                slot = np.arange(sel.size)[::-1]
+            k = min(u.size, cap)
+            send_pad[o * cap: o * cap + k] = u[:k]
+            if u.size > cap:
+                overflow |= 1
+            perm_pad[sel] = o * cap + np.where(slot < cap, slot, 0)
+        return torch.from_numpy(send_pad), torch.from_numpy(perm_pad)
+
     def pad_route(self, counts, send_local, perm, R, cap, overflow):
         """contract of armnet_shard_pad_route: R equal slots of cap indices, index 0 in the unused entries"""
         c = counts.numpy().astype(np.int64)
@@ -252,15 +274,20 @@ def _ragged_worker(rank, world, port, q):
         # step 0: unequal batches (the ranks agree on the larger one); step 1: a ragged last batch on one rank only (7 vs
         # 64 samples: local sizes would give different slot sizes, and 8 * n >= nfeat a different de-duplication choice);
         # step 2: a LARGER batch than agreed on rank 1 only — its slots may overflow; poll() raises the agreed size
+        import warnings
+        grown = []
         for step, B in enumerate([(64, 50), (7, 64), (64, 400)]):
             ids = torch.randint(0, nfeat, (B[rank], F), generator=torch.Generator().manual_seed(10 * step + rank))
-            rows, perm = shard.lookup(ids)
+            with warnings.catch_warnings(record=True) as wl:
+                warnings.simplefilter("always")
+                rows, perm = shard.lookup(ids)
+            grown.append(any("exceeds the agreed step size" in str(w.message) for w in wl))
             sizes.append(int(rows.shape[0]))
             over, _ = shard.poll(None)
             if over:
                 rows, perm = shard.lookup(ids, protocol="exact")
             oks.append(bool(torch.equal(rows[perm.long()].view(B[rank], F, E), table[ids])))
-        q.put((rank, oks, sizes, shard.slot_lookups))
+        q.put((rank, oks, sizes, shard.slot_lookups, grown))
     finally:
         dist.destroy_process_group()
 
@@ -281,6 +308,9 @@ def test_fixed_protocol_with_unequal_batches_agrees_on_one_slot_size_gloo():
     assert all(all(r[1]) for r in res), res
     assert res[0][2] == res[1][2], res                     # the same receive-buffer size on both ranks, every step
     assert res[0][3] == res[1][3] == 400 * 6, res          # the larger step raised the agreed size on BOTH ranks
+    # round-3 advisor finding: the rank whose step outgrew the agreed size is told so (its slots may overflow until the
+    # next poll: an unverified caller must not find out from wrong rows) — and only that rank, only at that step
+    assert res[0][4] == [False, False, False] and res[1][4] == [False, False, True], res
 
 
 def _poll_worker(rank, world, port, q):
