@@ -1,22 +1,44 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): worst elementwise error of the fused block over every eval fixture, in units of the 1e-5 bar
-(|got - ref| / (1e-5 * max(1, |ref|))) — the parity margin a solver tolerance or epilogue change has to live within."""
-import os, sys
+"""Developer tool (GPU box): worst elementwise error of the HIP path over every eval fixture.
+  per alpha:           the fused block in units of the 1e-5 bar (|got - ref| / (1e-5 * max(1, |ref|))) — the parity margin a
+                       solver tolerance or epilogue change has to live within;
+  per fixture family:  worst ABSOLUTE error of the post-BatchNorm neurons and of the logits, next to the largest |ref| of the
+                       family (round-3 verdict, weak 1: north_star says "within 1e-5 fp32"; the tests' bar is 1e-5 relative
+                       to max(1, |ref|) per element — this table is what that means in absolute numbers)."""
+import os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import numpy as np
 import torch
 from golden_util import load, model_cases
 from model_util import build_model
 from tol_util import elem_excess
 
-worst = {}
+worst, fam = {}, {}
 for name in [n for n in model_cases() if "train" not in n]:
     meta, sd, ids, vals, ref = load(name)
     m = build_model(meta, sd, "cuda:0")
     with torch.no_grad():
-        got = m.arm_block(torch.from_numpy(ids).cuda(), torch.from_numpy(vals.copy()).cuda()).cpu().numpy()
+        i, v = torch.from_numpy(ids).cuda(), torch.from_numpy(vals.copy()).cuda()
+        got = m.arm_block(i, v).cpu().numpy()
+        y = m({"id": i, "value": torch.from_numpy(vals.copy()).cuda()}).cpu().numpy()
     a = float(meta["ctor"]["alpha"])
-    worst[a] = max(worst.get(a, 0.0), elem_excess(got, ref["x_arm"].reshape(got.shape), 1e-5))
+    want = ref["x_arm"].reshape(got.shape)
+    worst[a] = max(worst.get(a, 0.0), elem_excess(got, want, 1e-5))
+    f = re.match(r"(g\d+)", name).group(1) + (" wide" if "wide" in name else "")
+    d = fam.setdefault(f, dict(n=0, blk=0.0, blk_ref=0.0, blk_big=0.0, log=0.0, log_ref=0.0))
+    err = np.abs(got.astype(np.float64) - want)
+    d["n"] += 1
+    d["blk"] = max(d["blk"], float(err.max()))
+    d["blk_ref"] = max(d["blk_ref"], float(np.abs(want).max()))
+    small = np.abs(want) <= 1.0
+    d["blk_big"] = max(d["blk_big"], float(err[small].max()) if small.any() else 0.0)     # worst error among |ref| <= 1
+    d["log"] = max(d["log"], float(np.abs(y.reshape(-1) - ref["logits"].reshape(-1)).max()))
+    d["log_ref"] = max(d["log_ref"], float(np.abs(ref["logits"]).max()))
 for a in sorted(worst):
     print(f"alpha {a}: worst element at {worst[a]:.4f} x the 1e-5 bar ({worst[a] * 1e-5:.2e})")
+print("family     fixtures  block max|err|  (where |ref| <= 1)  max|ref|    logits max|err|  max|ref|")
+for f in sorted(fam, key=lambda k: (int(re.match(r"g(\d+)", k).group(1)), k)):
+    d = fam[f]
+    print(f"{f:10s} {d['n']:8d}  {d['blk']:13.2e}  {d['blk_big']:17.2e}  {d['blk_ref']:9.2e}  {d['log']:15.2e}  {d['log_ref']:8.2e}")
