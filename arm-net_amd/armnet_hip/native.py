@@ -31,7 +31,7 @@ EXPORTS = (
     "armnet_scatter_add_f32", "armnet_mlp_head_supported", "armnet_mlp_packed_bytes", "armnet_mlp_pack_layer_f32",
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
-    "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed",
+    "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
 )
 
 _lib = None
@@ -434,13 +434,25 @@ def shard_route_fixed_ws_bytes(R, nfeat, dedup):
 def shard_route_fixed(n, ids, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, workspace=None, id_status=None):
     """routing of the fixed-capacity protocol in one call: send_pad [R*cap], perm_pad [n], counts [R], overflow flag"""
     _ids_ok(ids)
-    _i32_ok(send_pad=send_pad, perm_pad=perm_pad, counts=counts, overflow=overflow)
+    _i32_ok(send_pad=send_pad, counts=counts, overflow=overflow)
+    if perm_pad is not None:                 # None (dedup only): the position gather is left to shard_route_fixed_perm
+        _i32_ok(perm_pad=perm_pad)
     with _on(ids, send_pad, perm_pad, counts, overflow, workspace, id_status):
         check(load().armnet_shard_route_fixed(
             ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), ctypes.c_int64(cap),
             int(bool(dedup)), _ptr(send_pad), _ptr(perm_pad), _ptr(counts), _ptr(overflow), _ptr(id_status),
             _ptr(workspace), ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
             _stream()))
+
+
+def shard_route_fixed_perm(n, ids, R, nfeat, perm_pad, workspace):
+    """perm_pad[i] = position of id i's row, from the workspace a shard_route_fixed(dedup=True, perm_pad=None) call left"""
+    _ids_ok(ids)
+    _i32_ok(perm_pad=perm_pad)
+    with _on(ids, perm_pad, workspace):
+        check(load().armnet_shard_route_fixed_perm(
+            ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), _ptr(perm_pad), _ptr(workspace),
+            ctypes.c_int64(workspace.numel() * workspace.element_size()), _stream()))
 
 
 def shard_direct_perm(n, ids, R, nfeat, perm, id_status=None):

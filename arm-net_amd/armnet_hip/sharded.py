@@ -45,6 +45,7 @@ class HipShardOps:
     def __init__(self):
         self._ws = {}            # workspace of the de-duplicating route, reused across steps: one per (device, stream),
                                  # so that steps in flight on different streams never share it
+        self.overlap_perm = True # de-duplicating fixed route: the position gather on a side stream (see route_fixed)
 
     def route(self, ids_flat, R, nfeat, dedup=False, id_status=None):
         """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once.
@@ -81,23 +82,46 @@ class HipShardOps:
         native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
         return send_pad, perm_pad
 
-    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None):
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, defer_perm=False):
         """-> send_pad [R*cap], perm_pad [n] (armnet_shard_route_fixed: routing of the fixed-capacity protocol in one call —
-        one kernel without de-duplication, byte-map mark + chunk scan + emit + one position gather with it; round 4:
-        91 us -> see DESIGN.md for 2.56 M lookups).  overflow (int32[1]) |= 1 if a slot is too small."""
+        one kernel without de-duplication; byte-map mark + chunk sums + emit, then one position gather, with it).
+        overflow (int32[1]) |= 1 if a slot is too small.
+
+        With de-duplication the request list (send_pad) does not depend on the position gather that produces perm_pad, so
+        with defer_perm that gather runs on a SIDE stream: it overlaps the index exchange / owner-side gather / row exchange
+        that follow on the caller's stream.  perm_pad then carries the event the consumer HAS to wait for (`wait_perm`:
+        sharded_arm_block does); the next route on this stream waits for it too, because the gather reads the workspace
+        the next route overwrites.  Without defer_perm (the default) everything is in order on the caller's stream."""
         n = ids_flat.numel()
         dev = ids_flat.device
         buf = torch.empty(R * cap + R, device=dev, dtype=torch.int32)      # counts right behind the slots: one fill for both
         send_pad, counts = buf[:R * cap], buf[R * cap:]
         perm_pad = torch.empty(n, device=dev, dtype=torch.int32)
-        ws = None
-        if dedup:
-            need = native.shard_route_fixed_ws_bytes(R, nfeat, True)
-            key = (dev, torch.cuda.current_stream(dev).cuda_stream, "fixed")
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() < need:
-                ws = self._ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
-        native.shard_route_fixed(n, ids_flat, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, ws, id_status)
+        if not dedup:
+            native.shard_route_fixed(n, ids_flat, R, nfeat, cap, False, send_pad, perm_pad, counts, overflow, None, id_status)
+            return send_pad, perm_pad
+        cur = torch.cuda.current_stream(dev)
+        need = native.shard_route_fixed_ws_bytes(R, nfeat, True)
+        key = (dev, cur.cuda_stream, "fixed")
+        st = self._ws.get(key)
+        if st is None or st["ws"].numel() < need:
+            st = self._ws[key] = {"ws": torch.empty(need, device=dev, dtype=torch.uint8), "side": torch.cuda.Stream(device=dev),
+                                  "busy": None}
+        if st["busy"] is not None:
+            cur.wait_event(st["busy"])                 # the previous step's position gather still reads the workspace
+        native.shard_route_fixed(n, ids_flat, R, nfeat, cap, True, send_pad, None, counts, overflow, st["ws"], id_status)
+        if not (defer_perm and self.overlap_perm):
+            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"])
+            st["busy"] = None
+            return send_pad, perm_pad
+        side = st["side"]
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"])
+            st["busy"] = side.record_event()
+        ids_flat.record_stream(side)
+        perm_pad.record_stream(side)
+        perm_pad._armnet_ready = st["busy"]
         return send_pad, perm_pad
 
     def direct_perm(self, ids_flat, R, nfeat, id_status=None):
@@ -229,14 +253,16 @@ class RowShardedTable:
             self.slot_lookups = int(h[2].item())   # a larger step than the agreed one was seen somewhere: same value on every rank
         return bool(h[0].item()), bool(h[1].item())
 
-    def lookup(self, ids, id_status=None, protocol=None):
+    def lookup(self, ids, id_status=None, protocol=None, defer_perm=False):
         """ids [B, F] (this rank's samples) -> (rows, perm int32 [B*F]) with rows[perm[i]] = table[ids[i]].
-        id_status: optional int32[1] device flag, set when an id is out of range (the caller raises IndexError)."""
+        id_status: optional int32[1] device flag, set when an id is out of range (the caller raises IndexError).
+        defer_perm: the caller promises to pass perm through `wait_perm` before using it (the de-duplicating fixed route
+        then computes it on a side stream, beside the exchanges)."""
         if (protocol or self.protocol) == "fixed":
-            return self._lookup_fixed(ids, id_status)
+            return self._lookup_fixed(ids, id_status, defer_perm)
         return self._lookup_exact(ids, id_status)
 
-    def _lookup_fixed(self, ids, id_status=None):
+    def _lookup_fixed(self, ids, id_status=None, defer_perm=False):
         R = self.world
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
@@ -255,7 +281,13 @@ class RowShardedTable:
         self.last_path = "fixed"
         if n > 0 and self.fused_route and hasattr(self.ops, "route_fixed"):
             # the slots directly (round 4): no back-to-back layout in between, no separate pad pass
-            send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status)
+            # the position gather on a side stream pays when there are exchanges to hide it behind; on one rank it only
+            # competes with the owner-side gather for the memory system (measured: 182.5 us per step against 165.7 in order)
+            if defer_perm and R > 1 and isinstance(self.ops, HipShardOps):
+                send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status,
+                                                          defer_perm=True)
+            else:
+                send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status)
         else:
             if n == 0:                                     # an empty slice still takes part in the exchanges
                 counts = torch.zeros(R, device=dev, dtype=torch.int32)
@@ -347,6 +379,14 @@ class RowShardedTable:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
 
+def wait_perm(perm):
+    """make the current stream wait for a perm whose producer ran on a side stream (HipShardOps.route_fixed); returns perm"""
+    ev = getattr(perm, "_armnet_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream(perm.device).wait_event(ev)
+    return perm
+
+
 def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
                       write_clamped_vals=True, flags=0, micro_batches=None, check_ids=False, verify=None):
     """Fused a2..a9 with the table row-sharded over the process group.  Returns out [B, O, E].
@@ -383,8 +423,8 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
         return out
 
     if M <= 1 or not vals.is_cuda:
-        rows, perm = shard.lookup(ids, status)
-        return finish(arm_block_forward(perm.view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
+        rows, perm = shard.lookup(ids, status, defer_perm=True)
+        return finish(arm_block_forward(wait_perm(perm).view(B, F), vals, rows, q_fold, values, bn_scale, bn_shift, alpha,
                                         n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False,
                                         flags=flags))
     O, E = q_fold.shape
@@ -398,13 +438,13 @@ def sharded_arm_block(shard, ids, vals, q_fold, values, bn_scale, bn_shift, alph
     for m in range(M):
         lo, hi = m * step, min(B, (m + 1) * step)   # every rank runs M slices, possibly an empty last one
         with torch.cuda.stream(side):
-            rows, perm = shard.lookup(ids[lo:hi], status)
+            rows, perm = shard.lookup(ids[lo:hi], status, defer_perm=True)
             ready = side.record_event()
         if hi > lo:
             compute.wait_event(ready)
             rows.record_stream(compute)
             perm.record_stream(compute)
-            arm_block_forward(perm.view(hi - lo, F), vals[lo:hi], rows, q_fold, values, bn_scale, bn_shift, alpha,
+            arm_block_forward(wait_perm(perm).view(hi - lo, F), vals[lo:hi], rows, q_fold, values, bn_scale, bn_shift, alpha,
                               n_iter=n_iter, write_clamped_vals=write_clamped_vals, check_ids=False, flags=flags,
                               out=out[lo:hi])
     return finish(out)

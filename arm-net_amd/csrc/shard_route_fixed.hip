@@ -267,6 +267,24 @@ size_t shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
     return (size_t)P /* mark */ + (size_t)P * 4 /* pos */ + (size_t)nchunk * 8 /* sums, base */ + 256;
 }
 
+// the position gather of the de-duplicating route on its own: perm_pad[i] = pos[p(id_i)] from the workspace a preceding
+// armnet_shard_route_fixed(dedup = 1, perm_pad = NULL) left behind.  The request list (send_pad) does not depend on it, so
+// the caller may run it on a side stream beside the index exchange / owner-side gather (armnet_hip/sharded.py).
+int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
+                                  const void* ws, size_t ws_bytes, hipStream_t st) {
+    if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if (n == 0) return ARMNET_OK;
+    const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
+    if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
+    const OwnerMap om = make_owner_map(R);
+    const int32_t* pos = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(ws) + P);
+    const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
+    if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, pos, perm_pad);
+    else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, pos, perm_pad);
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
 int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow, int32_t* id_status,
                              void* ws, size_t ws_bytes, hipStream_t st) {
@@ -317,12 +335,8 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
         uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, base, counts, send_pad, pos, overflow);
     }
     ARMNET_LAUNCH_CHECK();
-    if (n > 0) {
-        if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, pos, perm_pad);
-        else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, pos, perm_pad);
-        ARMNET_LAUNCH_CHECK();
-    }
-    return ARMNET_OK;
+    if (perm_pad) return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, ws, ws_bytes, st);
+    return ARMNET_OK;                         // perm_pad == NULL: the caller runs armnet_shard_route_fixed_perm itself
 }
 
 }  // namespace armnet
@@ -338,9 +352,16 @@ extern "C" int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type,
                                         int dedup, int32_t* send_pad, int32_t* perm_pad, int32_t* counts,
                                         int32_t* overflow, int32_t* id_status, void* workspace, int64_t ws_bytes,
                                         void* stream) {
-    if (n < 0 || R < 1 || nfeat <= 0 || cap < 1 || !send_pad || !counts || !overflow || (n > 0 && (!ids || !perm_pad)))
+    if (n < 0 || R < 1 || nfeat <= 0 || cap < 1 || !send_pad || !counts || !overflow || (n > 0 && (!ids || (!perm_pad && !dedup))))
         return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
                                     workspace, (size_t)ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
+                                             const void* workspace, int64_t ws_bytes, void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, workspace, (size_t)ws_bytes, (hipStream_t)stream);
 }

@@ -253,8 +253,13 @@ int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts,
  * dedup == 0: every lookup is a request; slot positions are reserved with atomics, so send_pad / perm_pad may differ
  * from run to run — send_pad[perm_pad[i]] == id_i / R always holds; no workspace.  *id_status |= 1 for an id outside
  * [0, nfeat) (it reads row 0).  No reference counterpart (the reference is single-device).
+ * With dedup != 0, perm_pad may be NULL: the position gather perm_pad[i] = pos[(id % R, id / R)] is then left to
+ * armnet_shard_route_fixed_perm on the same workspace — the request list does not depend on it, so a caller can run it on a
+ * side stream beside the index exchange and the owner-side gather (the workspace must stay untouched until it is done).
  */
 int64_t armnet_shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup);
+int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
+                                  const void* workspace, int64_t ws_bytes, void* stream);
 int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
                              int32_t* id_status, void* workspace, int64_t ws_bytes, void* stream);
