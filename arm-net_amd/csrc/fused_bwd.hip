@@ -167,7 +167,9 @@ int launch_fused_bwd(const BwdArgs& a, hipStream_t st) {
         return ((((size_t)a.F * a.E + 3) & ~(size_t)3) + (((size_t)o * a.E + 3) & ~(size_t)3) +
                 2 * (size_t)a.F * (tpb + 1) + (size_t)o * a.F + (size_t)o * a.E + 2 * (size_t)a.F) * sizeof(float);
     };
-    const int slice = (a.O > 128 && lds_need(256, a.O < 256 ? a.O : 256) <= 150 * 1024) ? 256 : 128;
+    int slice = (a.O > 128 && lds_need(256, a.O < 256 ? a.O : 256) <= 150 * 1024) ? 256 : 128;
+    // wide rows x wide embeddings (nemb > 64 with 40+ fields, round 4): shorter neuron slices until one sample's tiles fit
+    while (slice > 16 && lds_need(128, a.O < slice ? a.O : slice) > 150 * 1024) slice /= 2;
     for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
         s.O = a.O - o0 < slice ? a.O - o0 : slice;

@@ -629,6 +629,26 @@ def test_shard_route_fixed_kernel_contract(R, dedup, cap_factor, dtype, nfeat, n
     assert int(status.item()) == 1
 
 
+@pytest.mark.parametrize("R,dtype", [(1, torch.int64), (8, torch.int32), (3, torch.int64)])
+def test_position_gather_on_a_side_stream_gives_the_in_order_result(R, dtype):
+    """armnet_shard_route_fixed(perm_pad = NULL) + armnet_shard_route_fixed_perm on a side stream (what ranks > 1 do beside
+    their exchanges): the same perm_pad as the one-call form, step after step on the same workspace — the next route
+    waits for the previous gather, which still reads the position table"""
+    from armnet_hip.sharded import HipShardOps, wait_perm
+    nfeat, n = 200_003, 39 * 4099
+    ops = HipShardOps()
+    cap = (nfeat + R - 1) // R
+    overflow = torch.zeros(1, device=DEV, dtype=torch.int32)
+    for step in range(4):
+        ids = torch.randint(0, nfeat, (n,), generator=torch.Generator().manual_seed(10 * R + step)).to(dtype).to(DEV)
+        sp0, pp0 = ops.route_fixed(ids, R, nfeat, cap, True, overflow)
+        sp1, pp1 = ops.route_fixed(ids, R, nfeat, cap, True, overflow, defer_perm=True)
+        assert getattr(pp1, "_armnet_ready", None) is not None
+        wait_perm(pp1)
+        assert torch.equal(sp0, sp1) and torch.equal(pp0, pp1), step
+    assert int(overflow.item()) == 0
+
+
 def test_row_sharded_step_is_bit_equal_with_the_fused_and_the_round3_routing():
     """both routings of the fixed protocol (armnet_shard_route_fixed | route + pad_route) feed the same rows to the fused
     kernel: bit-equal outputs, with and without de-duplication"""

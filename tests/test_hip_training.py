@@ -87,7 +87,7 @@ BWD_SWEEP = [(1, 4, 1, 2.0), (3, 10, 128, 2.0), (5, 6, 17, 1.7), (8, 16, 16, 1.5
              (39, 16, 32, 2.5), (3, 10, 128, 2.5), (22, 32, 20, 3.0), (10, 10, 40, 2.2),
              # nemb 65..128 on the matrix cores (round 4): up to 32 fields; wider samples stay on the shape-agnostic kernel
              (10, 100, 10, 1.7), (22, 72, 32, 2.0), (3, 128, 40, 1.5), (30, 65, 20, 1.0), (32, 128, 16, 2.0), (13, 101, 24, 2.5),
-             (39, 96, 32, 2.0)]
+             (39, 96, 32, 2.0), (48, 128, 70, 2.0), (44, 100, 96, 1.7)]   # (the last two: shape-agnostic kernel in short neuron slices)
 
 
 @pytest.mark.parametrize("F,E,O,alpha", BWD_SWEEP)

@@ -13,7 +13,9 @@ bwd = "--bwd" in sys.argv
 B, nfeat = 37, 53
 bad = n = 0
 for F in range(1, 49):
-    for E in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 20, 31, 32, 33, 48, 63, 64):
+    wide = "--wide" in sys.argv            # round 4: the nemb 65..128 family only
+    for E in ((65, 66, 67, 72, 80, 96, 97, 100, 120, 127, 128) if wide else
+              (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 20, 31, 32, 33, 48, 63, 64)):
         for O in (1, 7, 16, 24, 32, 40, 70):
             for alpha in (1.0, 1.5, 1.7, 2.0) + ((2.5,) if (F + E + O) % 5 == 0 else ()):
                 if native.fused_kernel_kind(F, E, O, alpha) != 1:
@@ -38,7 +40,11 @@ for F in range(1, 49):
                     outs = []
                     for flags in (native.F_FORCE_GENERIC, 0):
                         dt, dv, dq = torch.zeros_like(table), torch.zeros_like(values), torch.zeros_like(qf)
-                        native.fused_bwd(B, F, E, O, alpha, 50, flags, ids, vals, table, qf, values, zg, dz, dt, dv, dq)
+                        try:
+                            native.fused_bwd(B, F, E, O, alpha, 50, flags, ids, vals, table, qf, values, zg, dz, dt, dv, dq)
+                        except native.ArmnetNativeError as e:
+                            bad += 1
+                            print(f"BWD refused F={F} E={E} O={O} alpha={alpha} flags={flags}: {e}")
                         outs.append((dt, dv, dq))
                     for nm, a, b in zip(("d_table", "d_values", "d_qfold"), outs[1], outs[0]):
                         e2 = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
