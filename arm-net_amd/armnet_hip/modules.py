@@ -535,8 +535,11 @@ class _MLP(nn.Module):
     def eval_path(self):
         """which code runs the eval-mode head (reported by bench.py)"""
         if self.hip_head and self._hip_plan() is not None:
+            if self._dims[1] == 0:
+                return "armnet_linear_small_f32: the head is one Linear (nlayers = 0), a plain fp32 HIP kernel"
             return ("armnet_mlp_head_f32: ONE HIP kernel, bf16x3-split operands on v_mfma_f32_32x32x16_bf16 "
-                    "(6 cross products, fp32 accumulate), hidden layers chained in registers")
+                    "(6 cross products, fp32 accumulate), hidden layers chained in registers"
+                    + ("" if self._dims[3] == 1 else "; final Linear with several outputs by armnet_linear_small_f32"))
         return "torch/hipBLASLt fp32 GEMMs, BatchNorm folded into the weights, bias+ReLU epilogue"
 
     def invalidate(self):
@@ -556,23 +559,28 @@ class _MLP(nn.Module):
         the last hidden layer the first slice writes its share of the final Linear (has_final 1) and the others add
         theirs (has_final 2)."""
         ninput, nlayers, nhid, noutput = self._dims
-        if nlayers < 1 or noutput != 1 or nhid < 1:
+        if noutput < 1 or noutput > 16:
             return None
-        S = self.HIP_MAX_SLICE
+        if nlayers == 0:
+            return []                                  # one Linear(ninput, noutput): armnet_linear_small_f32 alone (round 4)
+        if nhid < 1:
+            return None
+        one = noutput == 1                             # several outputs: the hidden layers here, the final Linear(nhid, noutput)
+        S = self.HIP_MAX_SLICE                         # by armnet_linear_small_f32 on the last hidden activations (round 4)
         plan, i = [], 0
         if nhid <= S:
             if not native.mlp_head_supported(ninput, nhid, 1):
                 return None
             while i < nlayers:
                 n = 2 if nlayers - i >= 2 else 1
-                plan.append((i, n, 1 if i + n == nlayers else 0, 0, nhid))
+                plan.append((i, n, 1 if (i + n == nlayers and one) else 0, 0, nhid))
                 i += n
             return plan
         nsl = (nhid + S - 1) // S
         w = ((nhid + nsl - 1) // nsl + 31) // 32 * 32            # equal slices, whole 32-unit tiles
         for i in range(nlayers):
             for k, n0 in enumerate(range(0, nhid, w)):
-                last = i + 1 == nlayers
+                last = i + 1 == nlayers and one
                 plan.append((i, 1, (1 if k == 0 else 2) if last else 0, n0, min(nhid, n0 + w)))
         return plan
 
@@ -624,8 +632,13 @@ class _MLP(nn.Module):
 
     def _hip_forward(self, x, ens=None, logits=None):
         """ens / logits: see _pack — with `logits` given this head ADDS its (ensemble-weighted) output to them"""
-        nhid = self._dims[2]
+        ninput, nlayers, nhid, noutput = self._dims
         B = x.shape[0]
+        hidden, last = self._groups()
+        if nlayers == 0:                               # layers.py:79-80: the MLP is one Linear
+            y = torch.empty(B, noutput, device=x.device, dtype=torch.float32)
+            native.linear_small(x, last.weight.detach().contiguous(), last.bias.detach(), y)
+            return y
         NP = (nhid + 15) // 16 * 16
         cur, cur_layer = x, 0                          # activations feeding hidden layer `cur_layer`
         nxt = None
@@ -648,6 +661,10 @@ class _MLP(nn.Module):
                 if nxt is None:
                     nxt = torch.zeros(B, NP, device=x.device, dtype=torch.float32)   # pad columns stay zero
                 native.mlp_head(B, K0, n1 - n0, n, 0, cur, blob, nxt[:, n0:])
+        if noutput != 1:                               # layers.py:86-87 with several outputs, on the last hidden activations
+            y = torch.empty(B, noutput, device=x.device, dtype=torch.float32)
+            native.linear_small(nxt[:, :nhid], last.weight.detach().contiguous(), last.bias.detach(), y)
+            return y
         return logits.view(B, 1)
 
     def _fold(self):
@@ -727,7 +744,7 @@ def _fused_ensemble_tail(model, x, ids, v):
     if tuple(ens.weight.shape) != (1, 2) or x.dtype != torch.float32:
         return None
     for m in (m1, m2):
-        if not (m.fold_eval and m.hip_head and m._hip_plan() is not None):
+        if not (m.fold_eval and m.hip_head and m._hip_plan() and m._dims[3] == 1):     # (a non-empty launch plan: hidden layers)
             return None
     x_deep = model.deep_embedding({"id": ids, "value": v}, check_ids=False)      # sees the clamped values (armnet.py:94)
     logits = m1._hip_forward(x if x.stride(1) == 1 else x.contiguous(), ens=(ens, 0))

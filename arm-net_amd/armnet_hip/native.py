@@ -32,6 +32,7 @@ EXPORTS = (
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
+    "armnet_linear_small_f32",
 )
 
 _lib = None
@@ -358,6 +359,23 @@ def mlp_pack_layer(K0, nhid, n_hidden, slot, W, b, bn, packed):
                                                _ptr(b), _ptr(bw), _ptr(bb), _ptr(bm), _ptr(bv),
                                                ctypes.c_float(bn[4] if bn is not None else 0.0), _ptr(packed),
                                                _stream()))
+
+
+def linear_small(x, W, bias, out, scale=1.0, accumulate=False):
+    """out[b, n] (+)= (bias[n] + x[b, :] . W[n, :]) * scale for N <= 16 outputs (armnet_linear_small_f32)"""
+    _dev_f32(W, "W")
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ArmnetNativeError("x: expected a float32 [B, K] tensor with unit inner stride on the HIP device")
+    if not (out.is_cuda and out.dtype == torch.float32 and out.dim() == 2 and out.stride(1) == 1):
+        raise ArmnetNativeError("out: expected a float32 [B, N] tensor with unit inner stride on the HIP device")
+    B, K = x.shape
+    N = W.shape[0]
+    ldx = x.stride(0) if B > 1 else max(x.stride(0), K)
+    ldo = out.stride(0) if B > 1 else max(out.stride(0), N)
+    with _on(x, W, bias, out):
+        check(load().armnet_linear_small_f32(ctypes.c_int64(B), int(K), int(N), _ptr(x), ctypes.c_int64(ldx), _ptr(W),
+                                             _ptr(bias), ctypes.c_float(scale), _ptr(out), ctypes.c_int64(ldo),
+                                             int(bool(accumulate)), _stream()))
 
 
 def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):

@@ -330,6 +330,15 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
  *       x is read in whole 16-float k-steps: ldx >= 16 * ceil(K0 / 16), and the columns K0 .. of every row must be
  *       readable and finite (they meet zero weights).  A contiguous [B, K0] tensor qualifies when K0 % 16 == 0.
  */
+/*
+ * The head shapes without a matrix-core launch (csrc/linear_small.hip, round 4): a Linear with a handful of outputs,
+ * out[b, n] (+)= (bias[n] + sum_k x[b, k] W[n, k]) * scale, N <= 16 — the whole MLP when nlayers == 0
+ * (models/layers.py:79-80) and the final Linear(nhid, noutput) of a head with noutput > 1 (models/layers.py:86-87).
+ * x [B, K] row stride ldx, W [N, K] dense, bias [N] or NULL, out [B, N] row stride ldo; accumulate != 0 adds to out.
+ */
+int armnet_linear_small_f32(int64_t B, int K, int N, const float* x, int64_t ldx, const float* W, const float* bias,
+                            float scale, float* out, int64_t ldo, int accumulate, void* stream);
+
 int armnet_mlp_head_supported(int K0, int nhid, int n_hidden);
 int64_t armnet_mlp_packed_bytes(int K0, int nhid, int n_hidden);
 int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const float* W, int Kin, const float* b,

