@@ -119,6 +119,17 @@ class _EntmaxFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         Y, = ctx.saved_tensors
+        d = Y.shape[ctx.dim]
+        if Y.is_cuda and Y.dtype == torch.float32 and dY.dtype == torch.float32 and 2 * d * 65 * 4 <= 64 * 1024:
+            # one HIP pass (armnet_entmax_bwd_f32) instead of six ATen passes over the [.., d] tensors
+            nd = Y.dim()
+            last = ctx.dim % nd == nd - 1
+            Yc = (Y if last else Y.movedim(ctx.dim, -1)).contiguous()
+            dYc = (dY if last else dY.movedim(ctx.dim, -1)).contiguous()
+            dX = torch.empty_like(Yc)
+            if Yc.numel():
+                native.entmax_bwd(Yc.numel() // d, d, ctx.alpha, Yc, dYc, dX)
+            return (dX if last else dX.movedim(-1, ctx.dim)), None, None, None, None, None
         if ctx.alpha == 1.0:
             dX = Y * (dY - (Y * dY).sum(ctx.dim, keepdim=True))
         else:

@@ -181,7 +181,7 @@ class _LinearSplitKFn(torch.autograd.Function):
             dw = torch.bmm(dy.reshape(S, B // S, -1).transpose(1, 2), x.reshape(S, B // S, -1)).sum(0)
         else:
             dw = dy.t() @ x
-        return dx, dw, dy.sum(0)
+        return dx, dw, (dy.sum(0) if ctx.needs_input_grad[2] else None)
 
 
 class HipBatchNorm1d(nn.BatchNorm1d):

@@ -32,7 +32,7 @@ EXPORTS = (
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
-    "armnet_linear_small_f32",
+    "armnet_linear_small_f32", "armnet_entmax_bwd_f32",
 )
 
 _lib = None
@@ -211,6 +211,13 @@ def entmax(rows, d, alpha, n_iter, ensure_sum_one, flags, X, P):
     with _on(X, P):
         check(load().armnet_entmax_f32(ctypes.c_int64(rows), d, ctypes.c_float(alpha), int(n_iter),
                                        int(bool(ensure_sum_one)), ctypes.c_uint32(flags), _ptr(X), _ptr(P), _stream()))
+
+
+def entmax_bwd(rows, d, alpha, Y, dY, dX):
+    _dev_f32(Y, "Y"); _dev_f32(dY, "dY"); _dev_f32(dX, "dX")
+    with _on(Y, dY, dX):
+        check(load().armnet_entmax_bwd_f32(ctypes.c_int64(rows), int(d), ctypes.c_float(alpha), _ptr(Y), _ptr(dY), _ptr(dX),
+                                           _stream()))
 
 
 def shard_route_ws_bytes(n, R):

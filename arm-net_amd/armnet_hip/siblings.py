@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import native
 from .block import _require_cuda
-from .modules import HipBatchNorm1d, HipEmbedding, _MLP
+from .modules import HipBatchNorm1d, HipEmbedding, _LinearSplitKFn, _MLP
 
 
 class _VersionKey:
@@ -215,8 +215,13 @@ class GC_ARMModel(SiblingBase):
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E]
         x_exp = self.emb_bn(torch.exp(x_emb))                                    # channel = field (gc_arm.py:89)
         qb = torch.einsum("kxy,koy->kox", at.bilinear, at.Q).reshape(K * H, E)   # parameter-only fold of the bilinear form
-        gates = torch.matmul(x_emb, qb.t()).transpose(1, 2)                      # [B, K*H, F]
-        gates = gates + gates.sum(-1, keepdim=True)                              # global context = the gates' field sum
+        # (the weight gradient of this contraction is a [K*H, E] result reduced over B*F rows: split-K, like the heads')
+        zb = qb.new_zeros(K * H)
+        gates = _LinearSplitKFn.apply(x_emb.reshape(B * x_emb.shape[1], E), qb, zb).view(B, -1, K * H)      # [B, F, K*H]
+        # global context (gc_arm.py:37-41): the bilinear form of the FIELD SUM of x — the reference's own formulation, and a
+        # reduction over [B, F, E] instead of the 4x larger gate tensor
+        gc = _LinearSplitKFn.apply(x_emb.sum(1), qb, zb)                                                    # [B, K*H]
+        gates = (gates + gc.unsqueeze(1)).transpose(1, 2)                                                   # [B, K*H, F]
         p = entmax_forward(gates.contiguous(), self.alpha, dim=-1, n_iter=self.n_iter)
         w = p * at.values.reshape(1, K * H, -1)
         arm = torch.bmm(w, x_exp)                                                # [B, K*H, E]
@@ -286,6 +291,8 @@ class AFNModel(SiblingBase):
         """afn.py:61-69 as differentiable device ops; Dropout (afn.py:69) acts on the block's output"""
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E], positive after the clip
         x_log = self.emb_bn(torch.log(x_emb))                                    # channel = field
-        afn = torch.exp(self.afn(x_log.transpose(1, 2)))                         # [B,E,O]
+        Bq, Fq, Eq = x_log.shape                                                 # afn.py:64: Linear over the fields; its weight
+        lin = _LinearSplitKFn.apply(x_log.transpose(1, 2).reshape(Bq * Eq, Fq), self.afn.weight, self.afn.bias)   # gradient is a
+        afn = torch.exp(lin.view(Bq, Eq, -1))                                    # [O, F] result reduced over B*E rows: split-K
         afn = self.afn_bn(afn.transpose(1, 2).contiguous())                      # [B,O,E]
         return self.dropout(afn)

@@ -191,6 +191,13 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
     return launch_entmax(rows, d, cfg, X, P, (hipStream_t)stream);
 }
 
+int armnet_entmax_bwd_f32(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, void* stream) {
+    if (rows < 0 || d <= 0 || !(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
+    if (rows == 0) return ARMNET_OK;
+    if (!Y || !dY || !dX) return ARMNET_ERR_BAD_ARG;
+    return launch_entmax_bwd(rows, d, alpha, Y, dY, dX, (hipStream_t)stream);
+}
+
 int64_t armnet_shard_route_ws_bytes(int64_t n, int R) {
     if (n < 0 || R < 1) return -1;
     return (int64_t)shard_route_ws_bytes(n, R);

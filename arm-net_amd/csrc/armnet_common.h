@@ -337,6 +337,7 @@ int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, con
                         const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s);
 int launch_clamp_vals(float* vals, int64_t n, hipStream_t s);
 int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, float* P, hipStream_t s);
+int launch_entmax_bwd(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, hipStream_t s);
 size_t shard_route_ws_bytes(int64_t n, int R);
 int launch_shard_route(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* counts,
                        int32_t* send_local, int32_t* perm, void* ws, size_t ws_bytes, int32_t* id_status,

@@ -246,4 +246,75 @@ int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, 
     return ARMNET_OK;
 }
 
+// Backward of the stand-alone sparse map (utils/entmax.py:70-80), rows over the last dim:
+//   gppr = Y > 0 ? Y^(2 - alpha) : 0;  dX = dY * gppr;  q = sum(dX) / sum(gppr);  dX -= q * gppr
+// (alpha == 1: softmax, dX = Y * (dY - sum(Y * dY))).  Same transposing LDS staging as the forward: a block owns TPB
+// consecutive rows, reads Y and dY coalesced, thread r owns row r as an LDS column.  Replaces six ATen passes
+// (where, pow, two sums, two elementwise) over [B, neurons, fields] tensors in the sibling models' training step.
+template <int TPB>
+__global__ void entmax_bwd_lds_kernel(int64_t rows, int d, float alpha, const float* __restrict__ Y,
+                                      const float* __restrict__ dY, float* __restrict__ dX) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = TPB + 1;
+    float* ly = lds;
+    float* lg = lds + (size_t)d * S;
+    const float e = 2.0f - alpha;
+    for (int64_t r0 = (int64_t)blockIdx.x * TPB; r0 < rows; r0 += (int64_t)gridDim.x * TPB) {
+        const int nr = (int)((rows - r0) < TPB ? (rows - r0) : TPB);
+        const int n = nr * d;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += TPB) {
+            const int r = k / d, i = k - r * d;
+            ly[i * S + r] = Y[r0 * d + k];
+            lg[i * S + r] = dY[r0 * d + k];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nr) {
+            float* y = ly + threadIdx.x;
+            float* g = lg + threadIdx.x;
+            if (alpha == 1.0f) {
+                float dot = 0.f;
+                for (int i = 0; i < d; ++i) dot += y[i * S] * g[i * S];
+                for (int i = 0; i < d; ++i) g[i * S] = y[i * S] * (g[i * S] - dot);
+            } else {
+                float sx = 0.f, sg = 0.f;
+                for (int i = 0; i < d; ++i) {
+                    const float yy = y[i * S];
+                    const float gp = yy > 0.f ? (alpha == 2.0f ? 1.0f : powf(yy, e)) : 0.f;
+                    const float v = g[i * S] * gp;
+                    y[i * S] = gp;
+                    g[i * S] = v;
+                    sx += v;
+                    sg += gp;
+                }
+                const float q = sx / sg;
+                for (int i = 0; i < d; ++i) g[i * S] -= q * y[i * S];
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += TPB) {
+            const int r = k / d, i = k - r * d;
+            dX[r0 * d + k] = lg[i * S + r];
+        }
+    }
+}
+
+int launch_entmax_bwd(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, hipStream_t s) {
+    if (rows == 0) return ARMNET_OK;
+    const size_t lds128 = (size_t)2 * d * 129 * sizeof(float), lds64 = (size_t)2 * d * 65 * sizeof(float);
+    if (lds128 <= 64 * 1024) {
+        int64_t grid = (rows + 127) / 128;
+        if (grid > 256 * 8) grid = 256 * 8;
+        entmax_bwd_lds_kernel<128><<<(int)grid, 128, lds128, s>>>(rows, d, alpha, Y, dY, dX);
+    } else if (lds64 <= 64 * 1024) {
+        int64_t grid = (rows + 63) / 64;
+        if (grid > 256 * 8) grid = 256 * 8;
+        entmax_bwd_lds_kernel<64><<<(int)grid, 64, lds64, s>>>(rows, d, alpha, Y, dY, dX);
+    } else {
+        return ARMNET_ERR_UNSUPPORTED;
+    }
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
 }  // namespace armnet

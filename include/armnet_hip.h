@@ -146,6 +146,13 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
                       const float* X, float* P, void* stream);
 
 /*
+ * Backward of the sparse map w.r.t. its input (utils/entmax.py:70-80; softmax's Jacobian for alpha == 1), rows over the
+ * last dim: Y = the forward's output [rows, d], dY its gradient, dX [rows, d] (may alias dY).  The gradient w.r.t. alpha
+ * (entmax.py:81-98) is not provided: alpha is a float hyper-parameter on every call path of the reference's models.
+ */
+int armnet_entmax_bwd_f32(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, void* stream);
+
+/*
  * Backward of the fused block (training).  `z` is the forward's output computed with an
  * identity BatchNorm affine (bn_scale = 1, bn_shift = 0: the pre-BN neurons of armnet_1h.py:85-86; the
  * training-mode BatchNorm1d and the MLP stay with torch autograd), `dz` its gradient.  vals must already be
