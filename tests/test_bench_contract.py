@@ -120,7 +120,7 @@ def test_single_gpu_line_has_the_contract_keys_and_both_objects():
     assert set(oa) == {"1.7", "1.5", "note"} and oa["1.7"]["fresh"]["value"] > 1e6 and oa["1.5"]["stress"]["value"] > 1e6
     # the alpha = 2 headline (one solver evaluation, no transcendental) cannot be slower than alpha = 1.7 measured in the
     # same process on the same batches: if it is, the headline windows ran on a clock ramp (BENCH_r03)
-    assert d["ms_per_step"] <= 1.03 * oa["1.7"]["fresh"]["ms_per_step"], (d["ms_per_step"], oa["1.7"]["fresh"])
+    assert d["ms_per_step"] <= 1.05 * oa["1.7"]["fresh"]["ms_per_step"], (d["ms_per_step"], oa["1.7"]["fresh"])
     at = c["aten_chain"]                                               # the ATen op chain beside the C port
     assert at["value"] > 0 and at["cores"] == c["cores"] and "ATen op chain" in at["sample"]
     fl = d["batches_in_flight"]
