@@ -280,7 +280,7 @@ __global__ void entmax_bwd_lds_kernel(int64_t rows, int d, float alpha, const fl
                 float sx = 0.f, sg = 0.f;
                 for (int i = 0; i < d; ++i) {
                     const float yy = y[i * S];
-                    const float gp = yy > 0.f ? (alpha == 2.0f ? 1.0f : powf(yy, e)) : 0.f;
+                    const float gp = yy > 0.f ? (alpha == 2.0f ? 1.0f : alpha == 1.5f ? sqrtf(yy) : pow_pos(yy, e)) : 0.f;   // hardware log2 / exp2 (~2 ulp)
                     const float v = g[i * S] * gp;
                     y[i * S] = gp;
                     g[i * S] = v;
