@@ -14,7 +14,7 @@ bad = 0
 g = torch.Generator().manual_seed(123)
 for it in range(iters):
     for F, E, O, alpha, B in ((39, 16, 32, 2.0, 8192 + it), (39, 10, 128, 1.5, 3001), (22, 32, 40, 1.7, 4097), (43, 64, 24, 2.0, 2049),
-                              (3, 10, 128, 2.5, 1025)):
+                              (3, 10, 128, 2.5, 1025), (10, 100, 10, 1.7, 2049 + it), (22, 72, 32, 2.0, 1025), (39, 128, 16, 1.5, 513)):
         nfeat = 20011
         scale = 0.2 + 1.5 * float(torch.rand(1, generator=g))
         table = (torch.rand(nfeat, E, generator=g) * 1.6 - 0.8).to(DEV)
@@ -49,4 +49,4 @@ for it in range(iters):
                     print(f"it {it}: BWD F={F} E={E} O={O} alpha={alpha} {nm}: {e2}  ({rows} of {a.shape[0]} rows differ: a sample "
                           f"touches {F} table rows / 1 row of d_qfold per neuron -> support-boundary flips, not a kernel bug, "
                           f"when this stays a handful)")
-print(f"{iters} iterations x 5 shapes, {bad} disagreements")
+print(f"{iters} iterations x 8 shapes, {bad} disagreements")
