@@ -82,6 +82,8 @@ def parse():
                     help="slot slack of the fixed-capacity exchange in the configs[3] measurement")
     ap.add_argument("--no-config4", action="store_true",
                     help="N > 1: skip the extra row-sharded measurement of BASELINE.json configs[3] (nfeat 100 M, nemb 64)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="N > 1: skip the data-parallel measurement of BASELINE.json configs[4] (armnet + DNN ensemble, Avazu shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-alphas", action="store_true", help="skip the alpha = 1.7 / 1.5 measurements reported beside `value`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -703,6 +705,39 @@ def main():
         if not big["done"]:
             big["err"] = "timeout: the configs[3] measurement did not complete"
 
+    # BASELINE.json configs[4] — armnet + DNN ensemble (full models/armnet.py), Avazu shape (nfield 22, nfeat 2 M, nemb 32,
+    # 4 heads x 32), B = 131 072 GLOBAL, data-parallel: tables replicated (2 x 256 MB), the batch split over the ranks, no
+    # collective on the data path.  The whole forward to logits (fused block, second lookup, both heads with the ensemble
+    # Linear folded in).  N > 1 only (N = 1 stays configs[1]); never touches `value`.
+    c5 = {}
+    if a.shard == "both" and world > 1 and not a.no_config5 and sharded["done"] and (big["done"] or not big["err"]):
+        try:
+            a5 = argparse.Namespace(**vars(a))
+            a5.nhead, a5.nemb, a5.nfield, a5.nfeat, a5.ensemble, a5.shard = 4, 32, 22, 2_000_000, True, "replicate"
+            a5.batch = 131072 // world
+            m5 = build_model(a5, dev, rank, world, "fresh")
+            b5 = [make_batch(a5, rank, dev, k)[:2] for k in range(NB)]
+            t5 = [0]
+
+            def step5():
+                k = t5[0] % NB
+                t5[0] += 1
+                with torch.no_grad():
+                    return m5({"id": b5[k][0], "value": b5[k][1]})
+
+            settle_clocks(step5, min(a.settle_ms, 50.0), cap_ms=300.0)
+            w5 = []
+            for _ in range(3):
+                for _ in range(a.warmup):
+                    step5()
+                w5.append(timed(step5, a.steps, sync_all)[0])
+            t = torch.tensor(w5, device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c5 = {"ms": median(t.tolist()), "batch_per_rank": a5.batch}
+            del m5, b5
+        except Exception as e:  # noqa: BLE001
+            c5 = {"err": f"{type(e).__name__}: {e}"}
+
     # "pin alpha = 2.0 for the headline and report alpha = 1.7 (train.py's default) and 1.5 beside it": the same
     # block, batches and timing loop with the other sparse maps (N = 1 only; never `value`)
     other_alphas = {}
@@ -900,6 +935,13 @@ def main():
                             f"B={a.batch}/GPU, the 25.6 GB table row-sharded over the {world} ranks (never materialised "
                             f"whole), fused block per step; every sample needs {(world - 1) / world:.0%} of its "
                             f"{a.nfield} x 256-byte rows from other ranks"}
+        if c5:
+            line["config5_data_parallel"] = ({"error": c5["err"]} if "err" in c5 else {
+                "value": world * c5["batch_per_rank"] * a.steps / (c5["ms"] * 1e-3), "unit": "samples/s",
+                "ms_per_step": c5["ms"] / a.steps, "global_batch": world * c5["batch_per_rank"],
+                "note": f"BASELINE.json configs[4]: armnet (4 heads x 32) + DNN ensemble, nfield=22 nfeat=2000000 nemb=32, "
+                        f"B=131072 global = {c5['batch_per_rank']}/GPU, whole forward to logits, tables replicated, no data-path "
+                        f"collective; median of 3 windows of {a.steps} steps, MAX over ranks"})
         if a.shard == "rows":
             line["row_sharded_overflow"] = sharded_overflow
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":

@@ -143,6 +143,8 @@ def _check_two_rank_line(d):
     assert by["whole_shards"]["ingress_bytes_per_rank_per_step"] == 500_000 * 64     # the other rank's shard
     assert "row-sharded" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
+    c5 = d["config5_data_parallel"]                                    # BASELINE.json configs[4], data-parallel, beside the headline
+    assert "error" not in c5 and c5["global_batch"] == 131072 and c5["value"] > 1e5
 
 
 @pytest.mark.gpu
