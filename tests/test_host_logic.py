@@ -46,6 +46,18 @@ def test_abi_argument_validation_without_device():
     assert lib.armnet_scatter_add_f32(i64(8), 4, None, 0, None, None, i64(10), None, None) == native.ERR_BAD_ARG
     assert lib.armnet_fused_bwd_bn_f32(i64(8), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0,
                                        *([None] * 2), i64(100), *([None] * 11)) == native.ERR_BAD_ARG
+    # round 4 entry points: argument errors are answered without touching the device
+    f32 = ctypes.c_float
+    assert lib.armnet_shard_route_fixed(i64(8), None, 0, 2, i64(100), i64(16), 0, *([None] * 6), i64(0), None) == native.ERR_BAD_ARG
+    assert lib.armnet_shard_route_fixed_perm(i64(8), None, 0, 2, i64(100), None, None, i64(0), None) == native.ERR_BAD_ARG
+    lib.armnet_shard_route_fixed_ws_bytes.restype = ctypes.c_int64
+    assert lib.armnet_shard_route_fixed_ws_bytes(0, i64(100), 1) == -1 and lib.armnet_shard_route_fixed_ws_bytes(8, i64(1_000_000), 1) > 5_000_000
+    assert lib.armnet_linear_small_f32(i64(4), 8, 17, None, i64(8), None, None, f32(1.0), None, i64(17), 0, None) == native.ERR_UNSUPPORTED
+    assert lib.armnet_linear_small_f32(i64(4), 8, 2, None, i64(4), None, None, f32(1.0), None, i64(2), 0, None) == native.ERR_BAD_ARG   # ldx < K
+    assert lib.armnet_linear_small_f32(i64(0), 8, 2, None, i64(8), None, None, f32(1.0), None, i64(2), 0, None) == native.OK
+    assert lib.armnet_entmax_bwd_f32(i64(4), 0, f32(1.5), None, None, None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_entmax_bwd_f32(i64(4), 8, f32(0.5), None, None, None, None) == native.ERR_BAD_ARG
+    assert lib.armnet_entmax_bwd_f32(i64(0), 8, f32(1.5), None, None, None, None) == native.OK
     # an empty batch is a no-op even with null buffers
     assert lib.armnet_fused_fwd_f32(i64(0), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0, None, None,
                                     i64(100), *([None] * 7)) == native.OK
