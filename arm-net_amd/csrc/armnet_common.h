@@ -142,9 +142,15 @@ __device__ __forceinline__ float exp_accurate(float z) {
     return (e < INFINITY && e > 0.f) ? corr : e;          // keep inf / 0 / NaN untouched
 }
 
-// t ** pw for t > 0 through the hardware log2/exp2 pair (Newton solver only; ~2 ulp)
+// t ** pw for t > 0 through the hardware log2/exp2 pair (~2 ulp)
 __device__ __forceinline__ float pow_pos(float t, float pw) {
     return __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(t));
+}
+// clamp(t, 0) ** pw for pw > 0, NaN kept, as the bisection evaluates it (entmax.py:18-26,57): the same hardware pow the
+// matrix-core kernels use (log2(0) = -inf -> exp2(-inf) = 0).  Round 4: the literal bisection of the stand-alone map and
+// of the shape-agnostic kernel used libm powf — 11 ms for the headline's 2.1 M rows of 39 at alpha = 2.5
+__device__ __forceinline__ float pow_clamped(float t, float pw) {
+    return t != t ? t : __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(t > 0.f ? t : 0.f));
 }
 
 // In-place sparse map of ONE row held by ONE thread at x[0], x[stride], ... x[(d-1)*stride]
@@ -174,7 +180,7 @@ __device__ inline void sparse_map_row(float* x, int stride, int d, const SparseM
         float tau_lo = mx - 1.0f;                 // entmax.py:46
         const float tau_hi = mx - c.tau_hi_off;   // entmax.py:47
         float f_lo = 0.f;                         // entmax.py:49
-        for (int i = 0; i < d; ++i) f_lo += powf(clamp_min0(x[i * stride] - tau_lo), c.r);
+        for (int i = 0; i < d; ++i) f_lo += pow_clamped(x[i * stride] - tau_lo, c.r);
         f_lo -= 1.0f;
         float dm = tau_hi - tau_lo;               // entmax.py:51
         float tau_m = tau_lo;
@@ -185,13 +191,13 @@ __device__ inline void sparse_map_row(float* x, int stride, int d, const SparseM
             // below does it once more, so leaving here is bit-identical to running all n_iter steps
             if (tau_m == tau_lo) break;
             float s = 0.f;
-            for (int i = 0; i < d; ++i) s += powf(clamp_min0(x[i * stride] - tau_m), c.r);
+            for (int i = 0; i < d; ++i) s += pow_clamped(x[i * stride] - tau_m, c.r);
             const float f_m = s - 1.0f;
             if (f_m * f_lo >= 0.f) tau_lo = tau_m;
         }
         float s = 0.f;                            // p_m of the LAST tau_m, entmax.py:57,63-64
         for (int i = 0; i < d; ++i) {
-            float p = powf(clamp_min0(x[i * stride] - tau_m), c.r);
+            float p = pow_clamped(x[i * stride] - tau_m, c.r);
             x[i * stride] = p;
             s += p;
         }

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
                     gg[f * CS] = dp;
                     s1 += p * dp;
                 } else {
-                    const float gppr = p > 0.f ? (alpha == 2.0f ? 1.0f : (alpha == 1.5f ? sqrtf(p) : powf(p, 2.0f - alpha))) : 0.f;
+                    const float gppr = p > 0.f ? (alpha == 2.0f ? 1.0f : (alpha == 1.5f ? sqrtf(p) : pow_pos(p, 2.0f - alpha))) : 0.f;
                     const float dxp = dp * gppr;
                     gg[f * CS] = dxp;
                     s1 += dxp;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(TPB) fused_bwd_kernel(BwdArgs a, int S) {
                 if (alpha == 1.0f) {
                     gg[f * CS] = p * (gg[f * CS] - q);
                 } else {
-                    const float gppr = p > 0.f ? (alpha == 2.0f ? 1.0f : (alpha == 1.5f ? sqrtf(p) : powf(p, 2.0f - alpha))) : 0.f;
+                    const float gppr = p > 0.f ? (alpha == 2.0f ? 1.0f : (alpha == 1.5f ? sqrtf(p) : pow_pos(p, 2.0f - alpha))) : 0.f;
                     gg[f * CS] = gg[f * CS] - q * gppr;
                 }
                 pw[f * CS] = p * a.values[(size_t)o * F + f];
