@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
@@ -32,7 +32,7 @@ EXPORTS = (
     "armnet_mlp_head_f32", "armnet_gc_fused_fwd_f32", "armnet_afn_fused_fwd_f32", "armnet_fold_bn_f32",
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
-    "armnet_linear_small_f32", "armnet_entmax_bwd_f32",
+    "armnet_linear_small_f32", "armnet_entmax_bwd_f32", "armnet_gc_fused_bwd_supported", "armnet_gc_fused_bwd_f32",
 )
 
 _lib = None
@@ -279,6 +279,32 @@ def fused_bwd_bn(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, val
                                              _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _stream()))
 
 
+def gc_fused_bwd_supported(F, E, O):
+    return bool(load().armnet_gc_fused_bwd_supported(int(F), int(E), int(O)))
+
+
+def gc_fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, emb_scale, emb_shift, z, dy,
+                 coefA, coefB, coefC, d_table, d_values, d_qfold, d_y):
+    """armnet_gc_fused_bwd_f32 (include/armnet_hip.h): GC-ARM's block backward; coefA/B/C all None or all tensors"""
+    _ids_ok(ids)
+    ts = (vals, table, q_fold, values, emb_scale, emb_shift, z, dy, d_table, d_values, d_qfold, d_y)
+    for n, t in zip(("vals", "table", "q_fold", "values", "emb_scale", "emb_shift", "z", "dy", "d_table", "d_values",
+                     "d_qfold", "d_y"), ts):
+        _dev_f32(t, n)
+    coefs = (coefA, coefB, coefC)
+    if any(c is not None for c in coefs):
+        for n, t in zip(("coefA", "coefB", "coefC"), coefs):
+            _dev_f32(t, n)
+    if d_y.numel() != B * F * E:
+        raise ArmnetNativeError(f"d_y must hold B*F*E = {B * F * E} floats, got {d_y.numel()}")
+    with _on(ids, *ts):
+        check(load().armnet_gc_fused_bwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_float(alpha), int(n_iter),
+                                             ctypes.c_uint32(flags), _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                             ctypes.c_int64(table.shape[0]), _ptr(q_fold), _ptr(values), _ptr(emb_scale),
+                                             _ptr(emb_shift), _ptr(z), _ptr(dy), _ptr(coefA), _ptr(coefB), _ptr(coefC),
+                                             _ptr(d_table), _ptr(d_values), _ptr(d_qfold), _ptr(d_y), _stream()))
+
+
 def _ncl(x):
     if x.dim() == 2:
         return x.shape[0], x.shape[1], 1
@@ -303,6 +329,22 @@ def bn_forward_train(x, weight, bias, running_mean, running_var, momentum, eps, 
         check(lib.armnet_bn_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf[4]), _ptr(buf[5]), int(bool(relu)),
                                       _ptr(y), st))
     return y, buf[2], buf[3], buf[4], buf[5]
+
+
+def bn_train_stats(x, weight, bias, running_mean, running_var, momentum, eps):
+    """the statistics half of bn_forward_train (running statistics updated, nothing normalised): mean, rstd, scale,
+    shift of THIS batch — for a consumer that applies the affine itself (GC-ARM's fused block, siblings.py)"""
+    _dev_f32(x, "x")
+    N, C, L = _ncl(x)
+    with _on(x, weight, bias, running_mean, running_var):
+        buf = torch.zeros(6, C, device=x.device, dtype=torch.float32)
+        st = _stream()
+        lib = load()
+        check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
+        check(lib.armnet_bn_finalize_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(x), L, _ptr(weight), _ptr(bias),
+                                         ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
+                                         _ptr(running_var), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), st))
+    return buf[2], buf[3], buf[4], buf[5]
 
 
 def bn_backward_coef(x, dy, weight, mean, rstd, relu_scale=None, relu_shift=None):

@@ -124,6 +124,73 @@ class SiblingBase(nn.Module):
             raise IndexError("index out of range in self")
 
 
+def _bn_state(bn):
+    """(running_mean, running_var, momentum, eps) as the HIP BatchNorm passes take them (HipBatchNorm1d._hip_ok holds)"""
+    return bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps)
+
+
+class _GcBlockFn(torch.autograd.Function):
+    """GC-ARM's block in training mode (gc_arm.py:86-94 under train.py:108-114), fused (round 4):
+        forward   lookup * value -> exp -> emb_bn batch statistics (HIP passes) -> armnet_gc_fused_fwd_f32 with THIS batch's
+                  emb_bn affine and an identity arm_bn -> arm_bn training passes
+        backward  arm_bn reductions -> armnet_gc_fused_bwd_f32 (gates path straight into the table gradient, d_values,
+                  d_qfold, and the gradient of emb_bn's output) -> emb_bn backward passes -> * exp(x) -> scatter-add
+    The [B, K*H, F] gate / weight tensors of the composed path are never written."""
+
+    @staticmethod
+    def forward(ctx, table, bilinear, Q, values, emb_w, emb_b, arm_w, arm_b, ids, vals, cfg, emb_state, arm_state):
+        from .modules import _unit_affine
+        K, H, E, alpha, n_iter, flags, check_ids = cfg
+        B, F = vals.shape
+        O = K * H
+        dev = vals.device
+        status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
+        native.clamp_vals(vals)
+        x_emb = torch.empty(B, F, E, device=dev, dtype=torch.float32)
+        native.gather_scale(B * F, E, ids, vals, table.detach(), x_emb, status)
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("index out of range in self")
+        ex = torch.exp_(x_emb)                                               # gc_arm.py:89
+        e_mean, e_rstd, e_scale, e_shift = native.bn_train_stats(ex, emb_w.detach(), emb_b.detach(), *emb_state)
+        one, zero, sc, sh = _unit_affine(dev, O)
+        qf = torch.empty(O, E, device=dev, dtype=torch.float32)
+        native.fold_params(native.GC_ARM, K, H, E, E, bilinear.detach().contiguous(), Q.detach().contiguous(),
+                           one, zero, zero, one, 0.0, qf, sc, sh)
+        vflat = values.detach().reshape(O, F).contiguous()
+        z = torch.empty(B, O, E, device=dev, dtype=torch.float32)
+        native.gc_fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table.detach(), qf, vflat, e_scale, e_shift,
+                            one, zero, z, None)
+        y, a_mean, a_rstd, _, _ = native.bn_forward_train(z, arm_w.detach(), arm_b.detach(), *arm_state, relu=False)
+        ctx.save_for_backward(table, bilinear, Q, values, emb_w, arm_w, ids, vals, qf, vflat, z, ex, e_mean, e_rstd,
+                              e_scale, e_shift, a_mean, a_rstd)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .modules import _param_grad_buffers
+        (table, bilinear, Q, values, emb_w, arm_w, ids, vals, qf, vflat, z, ex, e_mean, e_rstd, e_scale, e_shift, a_mean,
+         a_rstd) = ctx.saved_tensors
+        K, H, E, alpha, n_iter, flags, _ = ctx.cfg
+        B, F = vals.shape
+        O = K * H
+        dy = dy.contiguous()
+        d_aw, d_ab, cA, cB, cC = native.bn_backward_coef(z, dy, arm_w.detach(), a_mean, a_rstd)
+        d_table = torch.zeros_like(table)
+        d_values, d_qf = _param_grad_buffers(O, F, E, dy.device)
+        d_y = torch.empty(B, F, E, device=dy.device, dtype=torch.float32)
+        native.gc_fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table.detach(), qf, vflat, e_scale, e_shift, z, dy,
+                            cA, cB, cC, d_table, d_values, d_qf, d_y)
+        d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(ex, d_y, emb_w.detach(), e_mean, e_rstd)
+        d_ex = native.bn_backward_apply(ex, d_y, eA, eB, eC)
+        d_ex.mul_(ex)                                                        # d exp(x) / dx = exp(x)
+        native.scatter_add(ids, vals, d_ex.view(B * F, E), d_table)
+        g3 = d_qf.view(K, H, E)                                              # q_fold[k,o,x] = sum_y bilinear[k,x,y] Q[k,o,y]
+        d_Q = torch.einsum("kox,kxy->koy", g3, bilinear)
+        d_bil = torch.einsum("kox,koy->kxy", g3, Q)
+        return (d_table, d_bil, d_Q, d_values.reshape(values.shape), d_ew, d_eb, d_aw, d_ab, None, None, None, None, None)
+
+
 class GC_SparseAttLayer(nn.Module):
     """Sparse attention with global context (gc_arm.py:6-48): Q [nhead, nhid, nemb], bilinear [nhead, nemb, nemb],
     values [nhead, nhid, nfield].  Called on x [B,F,E] it returns the attention weights [B,K,O,F] (stand-alone surface;
@@ -206,12 +273,30 @@ class GC_ARMModel(SiblingBase):
             return self._finish(self._arm_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.arm_block(ids, v_run), ids, v, v_run)
 
+    fused_training = True        # developer switch: False keeps the composed device ops for every shape
+
+    def _fused_training_ok(self, F):
+        """training mode (batch statistics in both BatchNorm1d layers, affine parameters present) on a shape the
+        matrix-core backward has a kernel for; everything else runs the composed device ops below"""
+        plain = all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                    for bn in (self.emb_bn, self.arm_bn))
+        return (self.fused_training and self.training and plain
+                and native.gc_fused_bwd_supported(F, self.nemb, self.nhead * self.arm_hid))
+
     def _arm_block_autograd(self, ids, v_run):
         """gc_arm.py:86-94 as differentiable device ops (train mode: batch statistics in both BatchNorm1d layers)"""
         from .block import entmax_forward
         B = v_run.shape[0]
         K, H, E = self.nhead, self.arm_hid, self.nemb
         at = self.attn_layers
+        if self._fused_training_ok(v_run.shape[1]):
+            cfg = (K, H, E, self.alpha, self.n_iter, self.kernel_flags, self.check_ids)
+            w = self.embedding.embedding.weight
+            self.emb_bn.num_batches_tracked.add_(1)
+            self.arm_bn.num_batches_tracked.add_(1)
+            return _GcBlockFn.apply(w, at.bilinear, at.Q, at.values, self.emb_bn.weight, self.emb_bn.bias,
+                                    self.arm_bn.weight, self.arm_bn.bias, ids, v_run, cfg, _bn_state(self.emb_bn),
+                                    _bn_state(self.arm_bn))
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E]
         x_exp = self.emb_bn(torch.exp(x_emb))                                    # channel = field (gc_arm.py:89)
         qb = torch.einsum("kxy,koy->kox", at.bilinear, at.Q).reshape(K * H, E)   # parameter-only fold of the bilinear form

@@ -44,8 +44,25 @@ namespace armnet {
 constexpr int bwd_passes(int E) { return E >= 128 ? 1 : E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : ARMNET_BWD_E16_PASSES; }
 constexpr int bwd_blocks_per_cu(int E) { return E >= 128 ? 1 : ARMNET_BWD_BLOCKS_PER_CU; }
 
-template <int E, int NQ, int MODE, int SRC>
-__global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kernel(BwdArgs a) {
+// MODEL_GC_ARM (models/gc_arm.py:82-95, round 4): the same kernel for GC-ARM's block
+//     arm[b,o,:] = sum_f w[b,o,f] y[b,f,:],   y = emb_bn(exp(x)) = emb_scale[f] * exp(x[b,f,:]) + emb_shift[f]   (no outer exp)
+//     w = entmax(g + sum_f g) * values        (the global context shifts every gate of a row by the same amount: the sparse
+//                                              map is shift-invariant, its Jacobian's rows sum to zero, and so does the
+//                                              context's gradient — analytically 0, rounding noise in the reference)
+//   ds = dz (not dz * z);  dW = y . ds with y formed from the staged rows as the forward does;  the two halves of MFMA #5
+//   go to different places: dg . q_fold is the gradient of x and is scattered into the table gradient here, w . ds is the
+//   gradient of y and is WRITTEN to d_y [B,F,E]: emb_bn runs on batch statistics in training, its backward needs the sums
+//   of d_y and d_y * y_hat over the whole batch before any of it can reach the table (the caller's BatchNorm passes).
+struct BwdExtra {
+    const float* emb_scale;   // [F]
+    const float* emb_shift;   // [F]
+    float* d_y;               // [B,F,E]
+    int accumulate;           // 0: d_y = ..., 1: d_y += ... (a later neuron slice of the same step)
+};
+
+template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
+__global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kernel(BwdArgs a, BwdExtra gx) {
+    constexpr bool GC = (MODEL == MODEL_GC_ARM);
     constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
     constexpr int ROWS = NTILE * 16;
     constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
@@ -77,6 +94,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     float* p_vv = p_bq + NT * EB * 64 * 4;    // [NT][NP][64] f32x2   values in the C layout
     float* qfl = p_vv + NT * NP * 64 * 2;     // [OP][ES]            q_fold, plain (B operand of MFMA #5)
     float* p_cf = qfl + OP * ES;              // [OP] f32x4 {A, B, C, -}: dz = A * dz_in + C * z + B (BatchNorm backward)
+    [[maybe_unused]] float* p_x = p_cf + OP * 4;   // GC-ARM: [ROWS] f32x2 {emb_scale, emb_shift} per field (0 past nfield)
     // block accumulators of the final flush: they ALIAS the wave-private regions (used only after every wave is done)
     float* acc_dv = lds_all;                  // [OP][FP]
     float* acc_dq = acc_dv + OP * FP;         // [OP][E]
@@ -161,6 +179,10 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     for (int i = threadIdx.x; i < OP * ES; i += 256) {
         const int o = i / ES, e = i - o * ES;
         qfl[i] = (o < O && e < Er) ? a.q_fold[(size_t)o * Er + e] : 0.f;
+    }
+    if constexpr (GC) {
+        for (int i = threadIdx.x; i < ROWS; i += 256)
+            *reinterpret_cast<f32x2*>(p_x + 2 * i) = i < F ? f32x2{gx.emb_scale[i], gx.emb_shift[i]} : f32x2{0.f, 0.f};
     }
     for (int i = threadIdx.x; i < OP; i += 256) {
         const bool on = a.bn_a != nullptr && i < O;
@@ -301,10 +323,14 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
         wave_lds_fence();
 
         f32x4 cdx[NTILE][EB];
+        [[maybe_unused]] f32x4 cdy[GC ? NTILE : 1][EB];              // GC-ARM: the gradient of y = emb_bn(exp(x))
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-            for (int eb = 0; eb < EB; ++eb) cdx[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int eb = 0; eb < EB; ++eb) {
+                cdx[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (GC) cdy[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) {
@@ -329,7 +355,15 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                     f32x4 dzv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dzv[r] = fmaf(cf[0], dN[eb][r], fmaf(cf[2], zN[eb][r], cf[1]));
-                    ds4[eb] = dzv * zN[eb];     // padding lanes (neuron >= O, e >= nemb) hold z = 0: ds = 0 whatever the shift
+                    if constexpr (GC) {
+                        // no outer exp (gc_arm.py:92-94): ds = dz.  Columns past nemb must not carry the BatchNorm shift
+                        // into the contraction over e (padding NEURONS hold {1, 0, 0} coefficients and dz = 0)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dzv[r] = (16 * eb + 4 * g + r < Er) ? dzv[r] : 0.f;
+                        ds4[eb] = dzv;
+                    } else {
+                        ds4[eb] = dzv * zN[eb]; // padding lanes (neuron >= O, e >= nemb) hold z = 0: ds = 0 whatever the shift
+                    }
                 }
             }
             if constexpr (PF >= 1) {
@@ -390,7 +424,14 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 wave_lds_fence();
                 const Red2 r = red_read(red, 0, c);
                 mx = vmax2(vmax3(r.g0[0], r.g1[0], r.g2[0]), r.g3[0]);
-                const float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                float sm = (r.g0[1] + r.g1[1]) + (r.g2[1] + r.g3[1]);
+                if constexpr (GC) {                         // global context: fused_mfma_kernel.h, gc_arm.py:37-41
+                    const float gcx = sm;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) XG(j) += gcx;
+                    mx += gcx;
+                    sm = fmaf((float)F, gcx, sm);
+                }
                 if constexpr (MODE == SOLVE_SOFTMAX) tau = mx + (sm - sm);
                 else if constexpr (MODE == SOLVE_BISECT) { tau = (mx - 1.0f) + (sm - sm); tau_hi = mx - tau_off; }
                 else tau = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
@@ -518,8 +559,16 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
             for (int kb = 0; kb < EB; ++kb) {
                 f32x4 av[NTILE];
 #pragma unroll
-                for (int t = 0; t < NTILE; ++t)
+                for (int t = 0; t < NTILE; ++t) {
                     av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                    if constexpr (GC) {
+                        // gc_arm.py:89-92: the interaction runs on y = emb_bn(exp(x)); tile row 16t + c is field
+                        // 16t + 4(c & 3) + (c >> 2) (pad rows: scale = shift = 0)
+                        const f32x2 es = *reinterpret_cast<const f32x2*>(p_x + 2 * (16 * t + 4 * (c & 3) + (c >> 2)));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) av[t][r] = fmaf(__builtin_amdgcn_exp2f(av[t][r] * L2E), es[0], es[1]);
+                    }
+                }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -616,8 +665,10 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 for (int t = 0; t < NTILE; ++t) {
                     const float a1 = tw[ol * RS + 16 * t + c];
 #pragma unroll
-                    for (int eb = 0; eb < EB; ++eb)
-                        cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdx[t][eb], 0, 0, 0);
+                    for (int eb = 0; eb < EB; ++eb) {
+                        if constexpr (GC) cdy[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdy[t][eb], 0, 0, 0);
+                        else cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdx[t][eb], 0, 0, 0);
+                    }
                 }
             }
             wave_lds_fence();
@@ -662,6 +713,19 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                     for (int eb = 0; eb < EB; ++eb)
                         if (16 * eb + c < Er) unsafeAtomicAdd(dst + 16 * eb, cdx[t][eb][r] * v);
                 }
+                if constexpr (GC) {
+                    // the gradient of y: every (sample, field, e) belongs to one lane of one wave — plain stores
+                    if (id != 0xffffffffu) {
+                        float* dy = gx.d_y + ((size_t)b * F + (16 * t + 4 * r + g)) * Er + c;
+#pragma unroll
+                        for (int eb = 0; eb < EB; ++eb)
+                            if (16 * eb + c < Er) {
+                                float v2 = cdy[t][eb][r];
+                                if (gx.accumulate) v2 += dy[16 * eb];
+                                dy[16 * eb] = v2;
+                            }
+                    }
+                }
             }
     }
     // ---- wave accumulators -> block accumulators (LDS atomics, once per wave) -> global ------------------------
@@ -692,13 +756,13 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     }
 }
 
-template <int E, int NQ, int MODE, int SRC>
-static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
+template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
+static int launch_bwd_one(const BwdArgs& a, const BwdExtra& gx, hipStream_t st) {
     constexpr int NTILE = (NQ + 3) / 4, ROWS = NTILE * 16;
     constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
     const int NT = (a.O + 15) / 16, OP = NT * 16;
     size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
-                  (size_t)OP * (E + 4) + (size_t)OP * 4) * sizeof(float);
+                  (size_t)OP * (E + 4) + (size_t)OP * 4 + (MODEL == MODEL_GC_ARM ? (size_t)2 * ROWS : 0)) * sizeof(float);
     if ((size_t)OP * (4 * NQ + E) > (size_t)4 * WAVE_FLOATS) return ARMNET_ERR_UNSUPPORTED;    // the aliased accumulators
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
 #ifdef ARMNET_DEV_FLAGS
@@ -709,22 +773,22 @@ static int launch_bwd_one(const BwdArgs& a, hipStream_t st) {
     const int64_t blocks = (a.B + 3) / 4;
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t want = blocks < resident ? blocks : resident;
-    auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC>;
+    auto kern = fused_bwd_mfma_kernel<E, NQ, MODE, SRC, MODEL>;
     ARMNET_ALLOW_BIG_LDS(kern, lds);
-    kern<<<(int)want, 256, lds, st>>>(a);
+    kern<<<(int)want, 256, lds, st>>>(a, gx);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
 
-template <int E, int NQ>
-static int launch_bwd_src(const BwdArgs& a, hipStream_t st) {
+template <int E, int NQ, int MODEL = MODEL_ARM>
+static int launch_bwd_src(const BwdArgs& a, hipStream_t st, const BwdExtra& gx = BwdExtra{}) {
 #define ARMNET_BWD_MODE(SRC)                                                                         \
     switch (a.cfg.mode) {                                                                            \
-        case SOLVE_SOFTMAX: return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, SRC>(a, st);             \
-        case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC>(a, st);           \
-        case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC>(a, st);           \
-        case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC>(a, st);               \
-        case SOLVE_BISECT: return launch_bwd_one<E, NQ, SOLVE_BISECT, SRC>(a, st);               \
+        case SOLVE_SOFTMAX: return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, SRC, MODEL>(a, gx, st);             \
+        case SOLVE_MICHELOT: return launch_bwd_one<E, NQ, SOLVE_MICHELOT, SRC, MODEL>(a, gx, st);           \
+        case SOLVE_NEWTON15: return launch_bwd_one<E, NQ, SOLVE_NEWTON15, SRC, MODEL>(a, gx, st);           \
+        case SOLVE_NEWTON: return launch_bwd_one<E, NQ, SOLVE_NEWTON, SRC, MODEL>(a, gx, st);               \
+        case SOLVE_BISECT: return launch_bwd_one<E, NQ, SOLVE_BISECT, SRC, MODEL>(a, gx, st);               \
         default: return ARMNET_ERR_UNSUPPORTED;                                                      \
     }
     if (a.id_type == ARMNET_ID_I64) { ARMNET_BWD_MODE(0) }
@@ -736,5 +800,8 @@ int launch_bwd_mfma_e16(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e32(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e64(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e128(const BwdArgs& a, int nq, hipStream_t st);    // nq 2..8 (wider samples do not fit the LDS)
+// GC-ARM (fused_bwd_gc_*.hip): nemb <= 32
+int launch_bwd_gc_e16(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
+int launch_bwd_gc_e32(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 
 }  // namespace armnet

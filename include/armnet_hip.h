@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: round-2 additions (prediction head, GC-ARM / AFN entry points, fixed-capacity and whole-shard routing helpers);
  * everything of version 1 is unchanged */
-#define ARMNET_ABI_VERSION 3
+#define ARMNET_ABI_VERSION 4
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
@@ -310,6 +310,32 @@ int armnet_afn_fused_fwd_f32(int64_t B, int F, int E, int O, uint32_t flags, con
 int armnet_fold_bn_f32(int C, const float* weight, const float* bias, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
 int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
+
+/*
+ * GC-ARM's block backward on the matrix cores (round 4) — the training step of `train.py:108-114 --model gc_arm`
+ * (models/gc_arm.py:82-95 under autograd), one kernel per slice of 64 (nemb <= 16) / 32 neurons:
+ *   inputs as armnet_gc_fused_fwd_f32; emb_scale / emb_shift = the affine emb_bn applies to exp(x) in THIS step
+ *   (training mode: from the batch statistics, armnet_bn_finalize_f32);  z = the pre-arm_bn block output of the forward
+ *   run with an identity bn_scale / bn_shift;  dy = the gradient of z, or — with coefA/B/C (armnet_bn_bwd_coef_f32, all
+ *   three or none) — the gradient of arm_bn's output, dz = coefA[o] * dy + coefC[o] * z + coefB[o] formed in the kernel.
+ * Outputs:
+ *   d_table  += the part of the table gradient that flows through the gates (x = table[id] * val -> g = x . q_fold)
+ *   d_values += , d_qfold +=     as armnet_fused_bwd_f32 (caller zero-initialises all three)
+ *   d_y [B,F,E] = the gradient of y = emb_bn(exp(x)) (overwritten).  emb_bn normalises with batch statistics, so
+ *                 its backward needs sums over the whole batch: the caller runs armnet_bn_bwd_reduce/coef/apply_f32 on
+ *                 (exp(x), d_y), multiplies by exp(x) and adds the result to d_table with armnet_scatter_add_f32.
+ * The global context (gc_arm.py:37-41) adds the same number to every gate of a row; the sparse map is invariant to
+ * that, its Jacobian's rows sum to zero, and the context's gradient is analytically zero (the reference's autograd
+ * produces rounding noise there) — it is not formed.
+ * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..32, nfield <= 48); otherwise
+ * ARMNET_ERR_UNSUPPORTED and the caller keeps its composed device ops.
+ */
+int armnet_gc_fused_bwd_supported(int F, int E, int O);
+int armnet_gc_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags, const void* ids,
+                            int id_type, const float* vals, const float* table, int64_t nfeat, const float* q_fold,
+                            const float* values, const float* emb_scale, const float* emb_shift, const float* z,
+                            const float* dy, const float* coefA, const float* coefB, const float* coefC,
+                            float* d_table, float* d_values, float* d_qfold, float* d_y, void* stream);
 
 /*
  * The eval-mode prediction head — models/layers.py:68-88 `MLP`: n x (Linear, BatchNorm1d, ReLU, Dropout) then

@@ -58,6 +58,13 @@ def test_abi_argument_validation_without_device():
     assert lib.armnet_entmax_bwd_f32(i64(4), 0, f32(1.5), None, None, None, None) == native.ERR_BAD_ARG
     assert lib.armnet_entmax_bwd_f32(i64(4), 8, f32(0.5), None, None, None, None) == native.ERR_BAD_ARG
     assert lib.armnet_entmax_bwd_f32(i64(0), 8, f32(1.5), None, None, None, None) == native.OK
+    # GC-ARM's block backward (round 4)
+    assert lib.armnet_gc_fused_bwd_supported(39, 16, 64) == 1 and lib.armnet_gc_fused_bwd_supported(39, 64, 64) == 0
+    assert lib.armnet_gc_fused_bwd_supported(49, 16, 64) == 0 and lib.armnet_gc_fused_bwd_supported(10, 3, 8) == 0
+    assert lib.armnet_gc_fused_bwd_f32(i64(8), 39, 16, 32, f32(2.0), 50, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
+                                       *([None] * 14)) == native.ERR_BAD_ARG
+    assert lib.armnet_gc_fused_bwd_f32(i64(0), 39, 16, 32, f32(2.0), 50, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
+                                       *([None] * 14)) == native.OK
     # an empty batch is a no-op even with null buffers
     assert lib.armnet_fused_fwd_f32(i64(0), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0, None, None,
                                     i64(100), *([None] * 7)) == native.OK

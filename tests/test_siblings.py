@@ -131,6 +131,66 @@ def test_sibling_training_step_matches_reference_gradients(name):
             np.testing.assert_allclose(got[k[6:]].cpu().numpy(), ref[k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+GC_FUSED_SHAPES = [  # nfield, nemb, nhead, arm_hid, alpha, batch  (one / several neuron slices, padded nemb, every solver)
+    (39, 16, 2, 32, 1.7, 512), (10, 10, 1, 20, 2.0, 300), (22, 32, 2, 8, 1.5, 257), (5, 8, 3, 7, 1.0, 130),
+    (43, 16, 1, 70, 2.5, 96), (48, 12, 4, 40, 2.0, 64), (3, 4, 1, 1, 1.3, 33), (30, 27, 2, 24, 1.5, 200),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,E,K,H,alpha,B", GC_FUSED_SHAPES)
+def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alpha, B):
+    """round-3 verdict, missing 3: GC-ARM's training step through armnet_gc_fused_bwd_f32 (matrix cores, no [B, K*H, F]
+    tensor in memory) against the same step through the composed device ops (the path the reference-gradient fixtures
+    pinned in round 3): logits, every gradient, both BatchNorm layers' running statistics"""
+    from armnet_hip import native
+    from armnet_hip.siblings import GC_ARMModel
+    assert native.gc_fused_bwd_supported(F, E, K * H)
+    nfeat = 997
+    g = torch.Generator().manual_seed(F * 131 + E)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 1.2 - 0.1).to(DEV)              # some outside [0.001, 1]: the clamp is live
+    y = (torch.rand(B, generator=g) > 0.5).float().to(DEV)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(7)
+        m = GC_ARMModel(F, nfeat, E, K, alpha, H, 2, 32, 0.0, True, 1, 16).to(DEV).train()
+        with torch.no_grad():                                                # trained-like: wide gates, non-trivial affines
+            m.embedding.embedding.weight.mul_(4.0)
+            m.attn_layers.Q.mul_(3.0)
+            for bn in (m.emb_bn, m.arm_bn):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+        m.fused_training = fused
+        assert m._fused_training_ok(F) == fused
+        v = vals.clone()
+        logits = m({"id": ids, "value": v})
+        torch.nn.BCEWithLogitsLoss()(logits, y).backward()
+        outs.append((logits.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()}, v))
+    (l0, g0, b0, v0), (l1, g1, b1, v1) = outs
+    assert torch.equal(v0, v1)
+    assert float((l0 - l1).abs().max()) <= 2e-5 * max(1.0, float(l0.abs().max())), "logits"
+    gmax = max(float(t.abs().max()) for t in g0.values())
+    rtol = 5e-4 if alpha > 2 else 5e-5                                       # alpha > 2: p^(2-alpha) near p = 0
+    worst = {}
+    for k in g0:
+        # a gradient's own scale, plus a floor for the analytically-zero ones (a bias in front of a train-mode BatchNorm:
+        # arm_bn.bias, the hidden Linears' biases — cancellation noise of sums over the batch in either path)
+        if float(g0[k].abs().max()) < 1e-5 * gmax:
+            continue                                                         # (the rule of the reference-gradient test above)
+        bar = rtol * float(g0[k].abs().max()) + 2e-6 * gmax
+        worst[k] = float((g0[k] - g1[k]).abs().max()) / bar
+    print({k: f"{v:.2f}" for k, v in worst.items() if v > 0.3})
+    for k, v in worst.items():
+        assert v <= 1.0, f"grad of {k}: {v:.2f} of the bar"
+    for k in b0:
+        if "running" in k:
+            torch.testing.assert_close(b1[k], b0[k], rtol=2e-5, atol=2e-6)
+        else:
+            assert torch.equal(b0[k], b1[k]), k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["gc", "afn"])
 def test_sibling_adam_steps_reduce_the_loss(kind):
