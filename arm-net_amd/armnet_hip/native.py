@@ -33,6 +33,7 @@ EXPORTS = (
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
     "armnet_linear_small_f32", "armnet_entmax_bwd_f32", "armnet_gc_fused_bwd_supported", "armnet_gc_fused_bwd_f32",
+    "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32",
 )
 
 _lib = None
@@ -329,6 +330,29 @@ def bn_forward_train(x, weight, bias, running_mean, running_var, momentum, eps, 
         check(lib.armnet_bn_apply_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf[4]), _ptr(buf[5]), int(bool(relu)),
                                       _ptr(y), st))
     return y, buf[2], buf[3], buf[4], buf[5]
+
+
+def afn_fused_bwd_supported(F, E, O):
+    return bool(load().armnet_afn_fused_bwd_supported(int(F), int(E), int(O)))
+
+
+def afn_fused_bwd(B, F, E, O, flags, ids, vals, table, weight, emb_scale, emb_shift, z, dy, coefA, coefB, coefC, d_weight,
+                  d_bias, d_y):
+    """armnet_afn_fused_bwd_f32 (include/armnet_hip.h): AFN's block backward; coefA/B/C all None or all tensors"""
+    _ids_ok(ids)
+    ts = (vals, table, weight, emb_scale, emb_shift, z, dy, d_weight, d_bias, d_y)
+    for n, t in zip(("vals", "table", "weight", "emb_scale", "emb_shift", "z", "dy", "d_weight", "d_bias", "d_y"), ts):
+        _dev_f32(t, n)
+    if any(c is not None for c in (coefA, coefB, coefC)):
+        for n, t in zip(("coefA", "coefB", "coefC"), (coefA, coefB, coefC)):
+            _dev_f32(t, n)
+    if d_y.numel() != B * F * E:
+        raise ArmnetNativeError(f"d_y must hold B*F*E = {B * F * E} floats, got {d_y.numel()}")
+    with _on(ids, *ts):
+        check(load().armnet_afn_fused_bwd_f32(ctypes.c_int64(B), F, E, O, ctypes.c_uint32(flags), _ptr(ids), _id_type(ids),
+                                              _ptr(vals), _ptr(table), ctypes.c_int64(table.shape[0]), _ptr(weight),
+                                              _ptr(emb_scale), _ptr(emb_shift), _ptr(z), _ptr(dy), _ptr(coefA), _ptr(coefB),
+                                              _ptr(coefC), _ptr(d_weight), _ptr(d_bias), _ptr(d_y), _stream()))
 
 
 def bn_train_stats(x, weight, bias, running_mean, running_var, momentum, eps):

@@ -191,6 +191,58 @@ class _GcBlockFn(torch.autograd.Function):
         return (d_table, d_bil, d_Q, d_values.reshape(values.shape), d_ew, d_eb, d_aw, d_ab, None, None, None, None, None)
 
 
+class _AfnBlockFn(torch.autograd.Function):
+    """AFN's block in training mode (afn.py:61-67 under train.py:108-114), fused (round 4): lookup * value -> log -> emb_bn batch
+    statistics -> armnet_afn_fused_fwd_f32 with THIS batch's emb_bn affine and an identity afn_bn -> afn_bn training passes;
+    backward: afn_bn reductions -> armnet_afn_fused_bwd_f32 (d afn.weight, d afn.bias, the gradient of emb_bn's output) ->
+    emb_bn backward passes -> / x -> scatter-add.  The table is already clipped (embedding_clip)."""
+
+    @staticmethod
+    def forward(ctx, table, weight, bias, emb_w, emb_b, afn_w, afn_b, ids, vals, cfg, emb_state, afn_state):
+        from .modules import _unit_affine
+        O, E, flags, check_ids = cfg
+        B, F = vals.shape
+        dev = vals.device
+        status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
+        native.clamp_vals(vals)
+        x_emb = torch.empty(B, F, E, device=dev, dtype=torch.float32)
+        native.gather_scale(B * F, E, ids, vals, table.detach(), x_emb, status)
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("index out of range in self")
+        lg = torch.log(x_emb)                                                # afn.py:63
+        l_mean, l_rstd, l_scale, l_shift = native.bn_train_stats(lg, emb_w.detach(), emb_b.detach(), *emb_state)
+        one, zero, _, _ = _unit_affine(dev, O)
+        wc = weight.detach().contiguous()
+        z = torch.empty(B, O, E, device=dev, dtype=torch.float32)
+        native.afn_fused_fwd(B, F, E, O, flags, ids, vals, table.detach(), wc, bias.detach(), l_scale, l_shift, one, zero, z,
+                             None)
+        y, a_mean, a_rstd, _, _ = native.bn_forward_train(z, afn_w.detach(), afn_b.detach(), *afn_state, relu=False)
+        ctx.save_for_backward(table, emb_w, afn_w, ids, vals, wc, z, x_emb, lg, l_mean, l_rstd, l_scale, l_shift, a_mean,
+                              a_rstd)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (table, emb_w, afn_w, ids, vals, wc, z, x_emb, lg, l_mean, l_rstd, l_scale, l_shift, a_mean,
+         a_rstd) = ctx.saved_tensors
+        O, E, flags, _ = ctx.cfg
+        B, F = vals.shape
+        dy = dy.contiguous()
+        d_aw, d_ab, cA, cB, cC = native.bn_backward_coef(z, dy, afn_w.detach(), a_mean, a_rstd)
+        buf = torch.zeros(O * (F + 1), device=dy.device, dtype=torch.float32)
+        d_weight, d_bias = buf[:O * F].view(O, F), buf[O * F:]
+        d_y = torch.empty(B, F, E, device=dy.device, dtype=torch.float32)
+        native.afn_fused_bwd(B, F, E, O, flags, ids, vals, table.detach(), wc, l_scale, l_shift, z, dy, cA, cB, cC, d_weight,
+                             d_bias, d_y)
+        d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(lg, d_y, emb_w.detach(), l_mean, l_rstd)
+        d_lg = native.bn_backward_apply(lg, d_y, eA, eB, eC)
+        d_lg.div_(x_emb)                                                     # d log(x) / dx = 1 / x
+        d_table = torch.zeros_like(table)
+        native.scatter_add(ids, vals, d_lg.view(B * F, E), d_table)
+        return d_table, d_weight, d_bias, d_ew, d_eb, d_aw, d_ab, None, None, None, None, None
+
+
 class GC_SparseAttLayer(nn.Module):
     """Sparse attention with global context (gc_arm.py:6-48): Q [nhead, nhid, nemb], bilinear [nhead, nemb, nemb],
     values [nhead, nhid, nfield].  Called on x [B,F,E] it returns the attention weights [B,K,O,F] (stand-alone surface;
@@ -372,8 +424,24 @@ class AFNModel(SiblingBase):
             return self._finish(self._afn_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.afn_block(ids, v_run), ids, v, v_run)
 
+    fused_training = True        # developer switch: False keeps the composed device ops for every shape
+
+    def _fused_training_ok(self, F):
+        plain = all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                    for bn in (self.emb_bn, self.afn_bn))
+        return (self.fused_training and self.training and plain
+                and native.afn_fused_bwd_supported(F, self.nemb, self.afn_hid))
+
     def _afn_block_autograd(self, ids, v_run):
         """afn.py:61-69 as differentiable device ops; Dropout (afn.py:69) acts on the block's output"""
+        if self._fused_training_ok(v_run.shape[1]):
+            cfg = (self.afn_hid, self.nemb, self.kernel_flags, self.check_ids)
+            self.emb_bn.num_batches_tracked.add_(1)
+            self.afn_bn.num_batches_tracked.add_(1)
+            afn = _AfnBlockFn.apply(self.embedding.embedding.weight, self.afn.weight, self.afn.bias, self.emb_bn.weight,
+                                    self.emb_bn.bias, self.afn_bn.weight, self.afn_bn.bias, ids, v_run, cfg,
+                                    _bn_state(self.emb_bn), _bn_state(self.afn_bn))
+            return self.dropout(afn)
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E], positive after the clip
         x_log = self.emb_bn(torch.log(x_emb))                                    # channel = field
         Bq, Fq, Eq = x_log.shape                                                 # afn.py:64: Linear over the fields; its weight

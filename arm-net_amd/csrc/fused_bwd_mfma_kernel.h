@@ -53,16 +53,24 @@ constexpr int bwd_blocks_per_cu(int E) { return E >= 128 ? 1 : ARMNET_BWD_BLOCKS
 //   go to different places: dg . q_fold is the gradient of x and is scattered into the table gradient here, w . ds is the
 //   gradient of y and is WRITTEN to d_y [B,F,E]: emb_bn runs on batch statistics in training, its backward needs the sums
 //   of d_y and d_y * y_hat over the whole batch before any of it can reach the table (the caller's BatchNorm passes).
+//
+// MODEL_AFN (models/afn.py:56-69): z[b,o,:] = exp(sum_f W[o,f] l[b,f,:] + bias[o]),  l = emb_bn(log(x)) = emb_scale[f] * log(x) +
+// emb_shift[f], W = afn.weight (BwdArgs.values).  No gates, no sparse map, no q_fold: per pass MFMA #3 (dW[f,o] = l . ds, summed
+// over the wave's samples like d_values), the bias gradient (row sums of ds) and the first half of MFMA #5 (dl = W^T ds, written
+// to d_y like GC-ARM's: emb_bn's backward needs whole-batch sums).  Nothing is scattered here (BwdArgs.d_table unused).
 struct BwdExtra {
     const float* emb_scale;   // [F]
     const float* emb_shift;   // [F]
     float* d_y;               // [B,F,E]
     int accumulate;           // 0: d_y = ..., 1: d_y += ... (a later neuron slice of the same step)
+    float* d_bias;            // AFN: [O] +=
 };
 
 template <int E, int NQ, int MODE, int SRC, int MODEL = MODEL_ARM>
 __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kernel(BwdArgs a, BwdExtra gx) {
     constexpr bool GC = (MODEL == MODEL_GC_ARM);
+    constexpr bool AFN = (MODEL == MODEL_AFN);
+    constexpr bool DY = GC || AFN;            // the gradient of the embedding BatchNorm's output goes to gx.d_y
     constexpr int NTILE = (NQ + 3) / 4;       // 16-row tiles per sample (last one may be half pad)
     constexpr int ROWS = NTILE * 16;
     constexpr int ES = E + 4;                 // LDS row stride of X, ds, q_fold (floats)
@@ -94,10 +102,11 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     float* p_vv = p_bq + NT * EB * 64 * 4;    // [NT][NP][64] f32x2   values in the C layout
     float* qfl = p_vv + NT * NP * 64 * 2;     // [OP][ES]            q_fold, plain (B operand of MFMA #5)
     float* p_cf = qfl + OP * ES;              // [OP] f32x4 {A, B, C, -}: dz = A * dz_in + C * z + B (BatchNorm backward)
-    [[maybe_unused]] float* p_x = p_cf + OP * 4;   // GC-ARM: [ROWS] f32x2 {emb_scale, emb_shift} per field (0 past nfield)
+    [[maybe_unused]] float* p_x = p_cf + OP * 4;   // GC-ARM / AFN: [ROWS] f32x2 {emb_scale, emb_shift} per field (0 past nfield)
     // block accumulators of the final flush: they ALIAS the wave-private regions (used only after every wave is done)
     float* acc_dv = lds_all;                  // [OP][FP]
     float* acc_dq = acc_dv + OP * FP;         // [OP][E]
+    [[maybe_unused]] float* acc_db = acc_dq + OP * E;   // AFN: [OP]
 
     const int Bi = (int)a.B;
     const int nwaves = (int)gridDim.x * 4;
@@ -157,7 +166,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
 #endif
 
     // ---- block prologue: parameters of this neuron slice, zeroed accumulators -------------------------
-    for (int i = threadIdx.x; i < NT * EB * 64; i += 256) {
+    for (int i = threadIdx.x; !AFN && i < NT * EB * 64; i += 256) {
         const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
         const int o = 16 * nt + (l & 15);
         const int e0 = 16 * kb + 4 * (l >> 4);
@@ -176,13 +185,18 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
         v[1] = (o < O && f1 < F) ? a.values[(size_t)o * F + f1] : 0.f;
         *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
     }
-    for (int i = threadIdx.x; i < OP * ES; i += 256) {
+    for (int i = threadIdx.x; !AFN && i < OP * ES; i += 256) {
         const int o = i / ES, e = i - o * ES;
         qfl[i] = (o < O && e < Er) ? a.q_fold[(size_t)o * Er + e] : 0.f;
     }
     if constexpr (GC) {
         for (int i = threadIdx.x; i < ROWS; i += 256)
             *reinterpret_cast<f32x2*>(p_x + 2 * i) = i < F ? f32x2{gx.emb_scale[i], gx.emb_shift[i]} : f32x2{0.f, 0.f};
+    }
+    if constexpr (AFN) {                      // log(x) = log2(x) * ln 2
+        for (int i = threadIdx.x; i < ROWS; i += 256)
+            *reinterpret_cast<f32x2*>(p_x + 2 * i) =
+                i < F ? f32x2{gx.emb_scale[i] * 0.693147182464599609375f, gx.emb_shift[i]} : f32x2{0.f, 0.f};
     }
     for (int i = threadIdx.x; i < OP; i += 256) {
         const bool on = a.bn_a != nullptr && i < O;
@@ -201,8 +215,10 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     constexpr int NTS = bwd_passes(E);
     f32x2 dvacc[NTS][NP];                     // pairs (2jp, 2jp+1) like the gate registers
     f32x4 dqacc[NTS][EB];
+    [[maybe_unused]] float dbacc[NTS];        // AFN: this lane's part of d_bias[16 nt + c]
 #pragma unroll
     for (int n = 0; n < NTS; ++n) {
+        dbacc[n] = 0.f;
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) dvacc[n][jp] = f32x2{0.f, 0.f};
 #pragma unroll
@@ -323,13 +339,13 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
         wave_lds_fence();
 
         f32x4 cdx[NTILE][EB];
-        [[maybe_unused]] f32x4 cdy[GC ? NTILE : 1][EB];              // GC-ARM: the gradient of y = emb_bn(exp(x))
+        [[maybe_unused]] f32x4 cdy[DY ? NTILE : 1][EB];              // GC-ARM / AFN: the gradient of emb_bn's output
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
 #pragma unroll
             for (int eb = 0; eb < EB; ++eb) {
                 cdx[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (GC) cdy[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (DY) cdy[t][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 
 #pragma unroll
@@ -370,10 +386,14 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 if (nt + 1 < npass) fetch_zd(b, nt + 1);
                 else fetch_zd(b + nwaves, 0);
             }
+            if constexpr (AFN) {
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) dbacc[nt] += (ds4[eb][0] + ds4[eb][1]) + (ds4[eb][2] + ds4[eb][3]);
+            }
             // ---- MFMA #1: gates -------------------------------------------------------------------------
             f32x4 c1[NTILE];
 #pragma unroll
-            for (int kb = 0; kb < EB; ++kb) {
+            for (int kb = 0; !AFN && kb < EB; ++kb) {
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
                 f32x4 av[NTILE];
 #pragma unroll
@@ -400,11 +420,17 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
             const float* vv_base = p_vv + (nt * NP * 64 + lane) * 2;
 #define VV(jp) (*reinterpret_cast<const f32x2*>(vv_base + (jp) * 128))
 
+            if constexpr (AFN) {                     // the [neurons, fields] weights are afn.weight itself
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t) c1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) XG(j) = VV(j >> 1)[j & 1];
+            }
             // ---- sparse map: p (normalised) left in the gate registers -------------------------------------
             wave_lds_fence();
-            float tau, Ssum = 1.0f;
+            float tau = 0.f, Ssum = 1.0f;
             [[maybe_unused]] float tau_hi = 0.f;
-            {
+            if constexpr (!AFN) {
                 f32x2 sm2;
 #pragma unroll
                 for (int jp = 0; jp < NP; ++jp) {
@@ -436,6 +462,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 else if constexpr (MODE == SOLVE_BISECT) { tau = (mx - 1.0f) + (sm - sm); tau_hi = mx - tau_off; }
                 else tau = vmax2(mx - 1.0f, fmaf(sm, invF, -tau_off)) + (sm - sm);
             }
+            if constexpr (!AFN) {
             if constexpr (MODE == SOLVE_SOFTMAX) {
                 wave_lds_fence();
                 float S = 0.f;
@@ -552,6 +579,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
 #pragma unroll
                 for (int jp = 0; jp < NP; ++jp) XP_SET(jp, XP_GET(jp) * r2);
             }
+            }   // !AFN
 
             // ---- MFMA #3: dW[f, o] = X[f, :] . ds[o, :] (layout of the gates) -------------------------------
             f32x4 c3[NTILE];
@@ -567,6 +595,16 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                         const f32x2 es = *reinterpret_cast<const f32x2*>(p_x + 2 * (16 * t + 4 * (c & 3) + (c >> 2)));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) av[t][r] = fmaf(__builtin_amdgcn_exp2f(av[t][r] * L2E), es[0], es[1]);
+                    }
+                    if constexpr (AFN) {
+                        // afn.py:63: l = emb_bn(log(x)); pad rows and columns past nemb hold 0 (log2 = -inf): selected away
+                        const int fr = 16 * t + 4 * (c & 3) + (c >> 2);
+                        const f32x2 es = *reinterpret_cast<const f32x2*>(p_x + 2 * fr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float lg = fmaf(__builtin_amdgcn_logf(av[t][r]), es[0], es[1]);
+                            av[t][r] = (fr < F && 16 * kb + 4 * g + r < Er) ? lg : 0.f;
+                        }
                     }
                 }
 #pragma unroll
@@ -606,8 +644,12 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 }
             };
             f32x2 s12 = {0.f, 0.f}, s22 = {0.f, 0.f};
+            if constexpr (AFN) {
 #pragma unroll
-            for (int jp = 0; jp < NP; ++jp) {
+                for (int jp = 0; jp < NP; ++jp) dvacc[nt][jp] += DP_GET(jp);      // d afn.weight[o, f]
+            }
+#pragma unroll
+            for (int jp = 0; !AFN && jp < NP; ++jp) {
                 const f32x2 p2 = XP_GET(jp), dW2 = DP_GET(jp), v2 = VV(jp);
                 dvacc[nt][jp] = __builtin_elementwise_fma(p2, dW2, dvacc[nt][jp]);
                 const f32x2 dp2 = v2 * dW2;
@@ -623,17 +665,17 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 }
             }
             wave_lds_fence();
-            red_write(red, 0, lane, s12[0] + s12[1], s22[0] + s22[1]);
+            if constexpr (!AFN) red_write(red, 0, lane, s12[0] + s12[1], s22[0] + s22[1]);
             wave_lds_fence();
-            float qv;
-            {
+            float qv = 0.f;
+            if constexpr (!AFN) {
                 const Red2 r = red_read(red, 0, c);
                 const f32x2 sd = (r.g0 + r.g1) + (r.g2 + r.g3);
                 qv = (MODE == SOLVE_SOFTMAX) ? sd[0] : sd[0] / sd[1];
             }
             const f32x2 nq2 = {-qv, -qv};
 #pragma unroll
-            for (int jp = 0; jp < NP; ++jp) {
+            for (int jp = 0; !AFN && jp < NP; ++jp) {
                 const f32x2 p2 = XP_GET(jp);
                 if constexpr (MODE == SOLVE_SOFTMAX) DP_SET(jp, p2 * (DP_GET(jp) + nq2));
                 else DP_SET(jp, __builtin_elementwise_fma(nq2, gppr(p2), DP_GET(jp)));
@@ -646,7 +688,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
             for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c1[t];
             // ---- MFMA #4: dq_fold^T[e, o] += sum_f X[f, e] dg[o, f], accumulated over the wave's samples ------
 #pragma unroll
-            for (int j = 0; j < NQ; ++j)
+            for (int j = 0; !AFN && j < NQ; ++j)
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
                     const int row = 16 * (j >> 2) + 4 * g + (j & 3);
@@ -666,17 +708,17 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                     const float a1 = tw[ol * RS + 16 * t + c];
 #pragma unroll
                     for (int eb = 0; eb < EB; ++eb) {
-                        if constexpr (GC) cdy[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdy[t][eb], 0, 0, 0);
+                        if constexpr (DY) cdy[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdy[t][eb], 0, 0, 0);
                         else cdx[t][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[eb], cdx[t][eb], 0, 0, 0);
                     }
                 }
             }
             wave_lds_fence();
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c3[t];
+            for (int t = 0; !AFN && t < NTILE; ++t) *reinterpret_cast<f32x4*>(tw + c * RS + 16 * t + 4 * g) = c3[t];
             wave_lds_fence();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; !AFN && kk < 4; ++kk) {
                 const int ol = 4 * kk + g;
                 float b2[EB];
 #pragma unroll
@@ -707,13 +749,13 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
                 const int row = 16 * t + 4 * g + r;
                 const uint32_t id = idl[row];
                 const float v = vll[row];
-                if (id != 0xffffffffu && !dbg_no_scatter) {
+                if (!AFN && id != 0xffffffffu && !dbg_no_scatter) {
                     float* dst = a.d_table + (size_t)id * Er + c;
 #pragma unroll
                     for (int eb = 0; eb < EB; ++eb)
                         if (16 * eb + c < Er) unsafeAtomicAdd(dst + 16 * eb, cdx[t][eb][r] * v);
                 }
-                if constexpr (GC) {
+                if constexpr (DY) {
                     // the gradient of y: every (sample, field, e) belongs to one lane of one wave — plain stores
                     if (id != 0xffffffffu) {
                         float* dy = gx.d_y + ((size_t)b * F + (16 * t + 4 * r + g)) * Er + c;
@@ -730,7 +772,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     }
     // ---- wave accumulators -> block accumulators (LDS atomics, once per wave) -> global ------------------------
     __syncthreads();                                                             // every wave is done with its region
-    for (int i = threadIdx.x; i < OP * (FP + E); i += 256) acc_dv[i] = 0.f;     // acc_dv and acc_dq are contiguous
+    for (int i = threadIdx.x; i < OP * (FP + E) + (AFN ? OP : 0); i += 256) acc_dv[i] = 0.f;     // acc_dv, acc_dq (, acc_db) are contiguous
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
@@ -738,6 +780,10 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
         float* dv_row = acc_dv + (16 * nt + c) * FP + g;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) atomicAdd(dv_row + 4 * j, dvacc[nt][j >> 1][j & 1]);   // pad slots receive zeros
+        if constexpr (AFN) {
+            atomicAdd(acc_db + 16 * nt + c, dbacc[nt]);
+            continue;
+        }
         float* dq_row = acc_dq + (16 * nt + c) * E + 4 * g;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb)
@@ -749,6 +795,10 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     for (int i = threadIdx.x; i < O * F; i += 256) {
         const int o = i / F, f = i - o * F;
         unsafeAtomicAdd(a.d_values + i, acc_dv[o * FP + f]);
+    }
+    if constexpr (AFN) {
+        for (int i = threadIdx.x; i < O; i += 256) unsafeAtomicAdd(gx.d_bias + i, acc_db[i]);
+        return;
     }
     for (int i = threadIdx.x; i < O * Er; i += 256) {
         const int o = i / Er, e = i - o * Er;
@@ -762,8 +812,8 @@ static int launch_bwd_one(const BwdArgs& a, const BwdExtra& gx, hipStream_t st) 
     constexpr int WAVE_FLOATS = ROWS * (E + 4) + 128 + 16 * (ROWS + 4) + 16 * (E + 4) + 2 * ROWS;
     const int NT = (a.O + 15) / 16, OP = NT * 16;
     size_t lds = ((size_t)4 * WAVE_FLOATS + (size_t)NT * (E / 16) * 256 + (size_t)NT * (NQ / 2) * 128 +
-                  (size_t)OP * (E + 4) + (size_t)OP * 4 + (MODEL == MODEL_GC_ARM ? (size_t)2 * ROWS : 0)) * sizeof(float);
-    if ((size_t)OP * (4 * NQ + E) > (size_t)4 * WAVE_FLOATS) return ARMNET_ERR_UNSUPPORTED;    // the aliased accumulators
+                  (size_t)OP * (E + 4) + (size_t)OP * 4 + (MODEL != MODEL_ARM ? (size_t)2 * ROWS : 0)) * sizeof(float);
+    if ((size_t)OP * (4 * NQ + E + 1) > (size_t)4 * WAVE_FLOATS) return ARMNET_ERR_UNSUPPORTED;    // the aliased accumulators
     if (lds > 160 * 1024) return ARMNET_ERR_UNSUPPORTED;
 #ifdef ARMNET_DEV_FLAGS
     if (const char* pad = getenv("ARMNET_BWD_LDS_PAD")) lds += (size_t)atoi(pad);     // developer knob: lower the occupancy
@@ -803,5 +853,12 @@ int launch_bwd_mfma_e128(const BwdArgs& a, int nq, hipStream_t st);    // nq 2..
 // GC-ARM (fused_bwd_gc_*.hip): nemb <= 32
 int launch_bwd_gc_e16(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 int launch_bwd_gc_e32(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
+
+// AFN (fused_bwd_afn.hip): nemb <= 32; no sparse map, so one solver-mode instantiation per shape
+template <int E, int NQ>
+static int launch_bwd_afn_t(const BwdArgs& a, const BwdExtra& gx, hipStream_t st) {
+    if (a.id_type == ARMNET_ID_I64) return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, 0, MODEL_AFN>(a, gx, st);
+    return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, 1, MODEL_AFN>(a, gx, st);
+}
 
 }  // namespace armnet

@@ -62,6 +62,6 @@ extern "C" int armnet_gc_fused_bwd_f32(int64_t B, int F, int E, int O, float alp
     a.cfg = make_sparse_cfg(alpha, n_iter, F, 1, flags);
     a.alpha = alpha;
     a.flags = flags;
-    BwdExtra gx{emb_scale, emb_shift, d_y, 0};
+    BwdExtra gx{emb_scale, emb_shift, d_y, 0, nullptr};
     return launch_gc_bwd(a, gx, (hipStream_t)stream);
 }

@@ -330,6 +330,19 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
  * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..32, nfield <= 48); otherwise
  * ARMNET_ERR_UNSUPPORTED and the caller keeps its composed device ops.
  */
+/*
+ * AFN's block backward (afn.py:56-69 under train.py:108-114), same kernel family:
+ *   l = emb_scale[f] * log(x) + emb_shift[f]  (this step's emb_bn affine of log(x));  z = exp(weight . l + bias) = the pre-afn_bn
+ *   output of armnet_afn_fused_fwd_f32 run with an identity bn_scale / bn_shift;  dy / coefA,B,C as above.
+ *   d_weight [O,F] += , d_bias [O] +=  (caller zero-initialises);  d_y [B,F,E] = the gradient of l (overwritten): the caller
+ *   runs emb_bn's backward passes on (log(x), d_y), divides by x and adds to the table gradient with armnet_scatter_add_f32.
+ */
+int armnet_afn_fused_bwd_supported(int F, int E, int O);
+int armnet_afn_fused_bwd_f32(int64_t B, int F, int E, int O, uint32_t flags, const void* ids, int id_type,
+                             const float* vals, const float* table, int64_t nfeat, const float* weight,
+                             const float* emb_scale, const float* emb_shift, const float* z, const float* dy,
+                             const float* coefA, const float* coefB, const float* coefC, float* d_weight,
+                             float* d_bias, float* d_y, void* stream);
 int armnet_gc_fused_bwd_supported(int F, int E, int O);
 int armnet_gc_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags, const void* ids,
                             int id_type, const float* vals, const float* table, int64_t nfeat, const float* q_fold,

@@ -65,6 +65,11 @@ def test_abi_argument_validation_without_device():
                                        *([None] * 14)) == native.ERR_BAD_ARG
     assert lib.armnet_gc_fused_bwd_f32(i64(0), 39, 16, 32, f32(2.0), 50, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
                                        *([None] * 14)) == native.OK
+    assert lib.armnet_afn_fused_bwd_supported(39, 16, 64) == 1 and lib.armnet_afn_fused_bwd_supported(39, 33, 64) == 0
+    assert lib.armnet_afn_fused_bwd_f32(i64(8), 39, 16, 32, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
+                                        *([None] * 12)) == native.ERR_BAD_ARG
+    assert lib.armnet_afn_fused_bwd_f32(i64(0), 39, 16, 32, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
+                                        *([None] * 12)) == native.OK
     # an empty batch is a no-op even with null buffers
     assert lib.armnet_fused_fwd_f32(i64(0), 39, 16, 32, ctypes.c_float(2.0), 50, ctypes.c_uint32(0), None, 0, None, None,
                                     i64(100), *([None] * 7)) == native.OK

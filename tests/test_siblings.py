@@ -131,6 +131,20 @@ def test_sibling_training_step_matches_reference_gradients(name):
             np.testing.assert_allclose(got[k[6:]].cpu().numpy(), ref[k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+def _analytically_zero(m):
+    """parameters whose gradient is zero up to the BatchNorm eps in a training step (cancellation noise in any fp32
+    implementation, the reference's included): a bias in front of a train-mode BatchNorm — the hidden Linears' biases,
+    arm_bn.bias / afn_bn.bias (followed by Linear -> BatchNorm) — and afn.bias (a per-channel scale of exp(.) in front of afn_bn)"""
+    names = {"arm_bn.bias", "afn_bn.bias", "afn.bias"}
+    for pref, seq in m.named_modules():
+        if isinstance(seq, torch.nn.Sequential):
+            mods = list(seq)
+            for i in range(len(mods) - 1):
+                if isinstance(mods[i], torch.nn.Linear) and isinstance(mods[i + 1], torch.nn.BatchNorm1d):
+                    names.add(f"{pref}.{i}.bias")
+    return names
+
+
 GC_FUSED_SHAPES = [  # nfield, nemb, nhead, arm_hid, alpha, batch  (one / several neuron slices, padded nemb, every solver)
     (39, 16, 2, 32, 1.7, 512), (10, 10, 1, 20, 2.0, 300), (22, 32, 2, 8, 1.5, 257), (5, 8, 3, 7, 1.0, 130),
     (43, 16, 1, 70, 2.5, 96), (48, 12, 4, 40, 2.0, 64), (3, 4, 1, 1, 1.3, 33), (30, 27, 2, 24, 1.5, 200),
@@ -162,6 +176,7 @@ def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alph
                 bn.weight.uniform_(0.5, 1.5)
                 bn.bias.uniform_(-0.3, 0.3)
         m.fused_training = fused
+        zero_names = _analytically_zero(m)
         assert m._fused_training_ok(F) == fused
         v = vals.clone()
         logits = m({"id": ids, "value": v})
@@ -175,11 +190,59 @@ def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alph
     rtol = 5e-4 if alpha > 2 else 5e-5                                       # alpha > 2: p^(2-alpha) near p = 0
     worst = {}
     for k in g0:
-        # a gradient's own scale, plus a floor for the analytically-zero ones (a bias in front of a train-mode BatchNorm:
-        # arm_bn.bias, the hidden Linears' biases — cancellation noise of sums over the batch in either path)
-        if float(g0[k].abs().max()) < 1e-5 * gmax:
-            continue                                                         # (the rule of the reference-gradient test above)
+        if k in zero_names or float(g0[k].abs().max()) < 1e-5 * gmax:
+            continue
         bar = rtol * float(g0[k].abs().max()) + 2e-6 * gmax
+        worst[k] = float((g0[k] - g1[k]).abs().max()) / bar
+    print({k: f"{v:.2f}" for k, v in worst.items() if v > 0.3})
+    for k, v in worst.items():
+        assert v <= 1.0, f"grad of {k}: {v:.2f} of the bar"
+    for k in b0:
+        if "running" in k:
+            torch.testing.assert_close(b1[k], b0[k], rtol=2e-5, atol=2e-6)
+        else:
+            assert torch.equal(b0[k], b1[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,E,O,B", [(39, 16, 64, 512), (10, 10, 20, 300), (22, 32, 40, 257), (5, 8, 7, 130), (43, 16, 70, 96),
+                                     (48, 12, 100, 64), (3, 4, 1, 33), (30, 27, 24, 200)])
+def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
+    """AFN's training step through armnet_afn_fused_bwd_f32 against the composed device ops (see the GC-ARM test above)"""
+    from armnet_hip import native
+    from armnet_hip.siblings import AFNModel
+    assert native.afn_fused_bwd_supported(F, E, O)
+    nfeat = 997
+    g = torch.Generator().manual_seed(F * 131 + E)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 1.2 - 0.1).to(DEV)
+    y = (torch.rand(B, generator=g) > 0.5).float().to(DEV)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(7)
+        m = AFNModel(F, nfeat, E, O, 2, 32, 0.0, True, 1, 16).to(DEV).train()
+        with torch.no_grad():
+            for bn in (m.emb_bn, m.afn_bn):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+            m.afn.bias.uniform_(-0.2, 0.2)
+        m.fused_training = fused
+        zero_names = _analytically_zero(m)
+        assert m._fused_training_ok(F) == fused
+        v = vals.clone()
+        logits = m({"id": ids, "value": v})
+        torch.nn.BCEWithLogitsLoss()(logits, y).backward()
+        outs.append((logits.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()}, v))
+    (l0, g0, b0, v0), (l1, g1, b1, v1) = outs
+    assert torch.equal(v0, v1)
+    assert float((l0 - l1).abs().max()) <= 2e-5 * max(1.0, float(l0.abs().max())), "logits"
+    gmax = max(float(t.abs().max()) for t in g0.values())
+    worst = {}
+    for k in g0:
+        if k in zero_names or float(g0[k].abs().max()) < 1e-5 * gmax:
+            continue
+        bar = 5e-5 * float(g0[k].abs().max()) + 2e-6 * gmax
         worst[k] = float((g0[k] - g1[k]).abs().max()) / bar
     print({k: f"{v:.2f}" for k, v in worst.items() if v > 0.3})
     for k, v in worst.items():
