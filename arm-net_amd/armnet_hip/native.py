@@ -33,7 +33,7 @@ EXPORTS = (
     "armnet_abs_clamp_min_f32", "armnet_shard_pad_route", "armnet_shard_direct_perm",
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
     "armnet_linear_small_f32", "armnet_entmax_bwd_f32", "armnet_gc_fused_bwd_supported", "armnet_gc_fused_bwd_f32",
-    "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32",
+    "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32", "armnet_bn_bwd_scatter_f32",
 )
 
 _lib = None
@@ -353,6 +353,21 @@ def afn_fused_bwd(B, F, E, O, flags, ids, vals, table, weight, emb_scale, emb_sh
                                               _ptr(vals), _ptr(table), ctypes.c_int64(table.shape[0]), _ptr(weight),
                                               _ptr(emb_scale), _ptr(emb_shift), _ptr(z), _ptr(dy), _ptr(coefA), _ptr(coefB),
                                               _ptr(coefC), _ptr(d_weight), _ptr(d_bias), _ptr(d_y), _stream()))
+
+
+def bn_bwd_scatter(ids, vals, t, dy, coefA, coefB, coefC, map_kind, d_table):
+    """armnet_bn_bwd_scatter_f32: t [B,F,E] = exp(x) (map_kind 0) or log(x) (1), dy its BatchNorm output's gradient"""
+    _ids_ok(ids)
+    ts = (vals, t, dy, coefA, coefB, coefC, d_table)
+    for n, x in zip(("vals", "t", "dy", "coefA", "coefB", "coefC", "d_table"), ts):
+        _dev_f32(x, n)
+    B, F, E = t.shape
+    if dy.shape != t.shape or vals.numel() != B * F or ids.numel() != B * F or d_table.shape[1] != E:
+        raise ArmnetNativeError("bn_bwd_scatter: shapes of ids / vals / t / dy / d_table disagree")
+    with _on(ids, *ts):
+        check(load().armnet_bn_bwd_scatter_f32(ctypes.c_int64(B * F), F, E, _ptr(ids), _id_type(ids), _ptr(vals), _ptr(t),
+                                               _ptr(dy), _ptr(coefA), _ptr(coefB), _ptr(coefC), int(map_kind),
+                                               ctypes.c_int64(d_table.shape[0]), _ptr(d_table), _stream()))
 
 
 def bn_train_stats(x, weight, bias, running_mean, running_var, momentum, eps):

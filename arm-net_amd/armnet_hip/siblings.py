@@ -182,9 +182,7 @@ class _GcBlockFn(torch.autograd.Function):
         native.gc_fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table.detach(), qf, vflat, e_scale, e_shift, z, dy,
                             cA, cB, cC, d_table, d_values, d_qf, d_y)
         d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(ex, d_y, emb_w.detach(), e_mean, e_rstd)
-        d_ex = native.bn_backward_apply(ex, d_y, eA, eB, eC)
-        d_ex.mul_(ex)                                                        # d exp(x) / dx = exp(x)
-        native.scatter_add(ids, vals, d_ex.view(B * F, E), d_table)
+        native.bn_bwd_scatter(ids, vals, ex, d_y, eA, eB, eC, 0, d_table)     # emb_bn backward, * exp(x), * value, scatter-add
         g3 = d_qf.view(K, H, E)                                              # q_fold[k,o,x] = sum_y bilinear[k,x,y] Q[k,o,y]
         d_Q = torch.einsum("kox,kxy->koy", g3, bilinear)
         d_bil = torch.einsum("kox,koy->kxy", g3, Q)
@@ -209,7 +207,7 @@ class _AfnBlockFn(torch.autograd.Function):
         native.gather_scale(B * F, E, ids, vals, table.detach(), x_emb, status)
         if status is not None and int(status.item()) != 0:
             raise IndexError("index out of range in self")
-        lg = torch.log(x_emb)                                                # afn.py:63
+        lg = torch.log_(x_emb)                                               # afn.py:63
         l_mean, l_rstd, l_scale, l_shift = native.bn_train_stats(lg, emb_w.detach(), emb_b.detach(), *emb_state)
         one, zero, _, _ = _unit_affine(dev, O)
         wc = weight.detach().contiguous()
@@ -217,15 +215,13 @@ class _AfnBlockFn(torch.autograd.Function):
         native.afn_fused_fwd(B, F, E, O, flags, ids, vals, table.detach(), wc, bias.detach(), l_scale, l_shift, one, zero, z,
                              None)
         y, a_mean, a_rstd, _, _ = native.bn_forward_train(z, afn_w.detach(), afn_b.detach(), *afn_state, relu=False)
-        ctx.save_for_backward(table, emb_w, afn_w, ids, vals, wc, z, x_emb, lg, l_mean, l_rstd, l_scale, l_shift, a_mean,
-                              a_rstd)
+        ctx.save_for_backward(table, emb_w, afn_w, ids, vals, wc, z, lg, l_mean, l_rstd, l_scale, l_shift, a_mean, a_rstd)
         ctx.cfg = cfg
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (table, emb_w, afn_w, ids, vals, wc, z, x_emb, lg, l_mean, l_rstd, l_scale, l_shift, a_mean,
-         a_rstd) = ctx.saved_tensors
+        table, emb_w, afn_w, ids, vals, wc, z, lg, l_mean, l_rstd, l_scale, l_shift, a_mean, a_rstd = ctx.saved_tensors
         O, E, flags, _ = ctx.cfg
         B, F = vals.shape
         dy = dy.contiguous()
@@ -236,10 +232,8 @@ class _AfnBlockFn(torch.autograd.Function):
         native.afn_fused_bwd(B, F, E, O, flags, ids, vals, table.detach(), wc, l_scale, l_shift, z, dy, cA, cB, cC, d_weight,
                              d_bias, d_y)
         d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(lg, d_y, emb_w.detach(), l_mean, l_rstd)
-        d_lg = native.bn_backward_apply(lg, d_y, eA, eB, eC)
-        d_lg.div_(x_emb)                                                     # d log(x) / dx = 1 / x
         d_table = torch.zeros_like(table)
-        native.scatter_add(ids, vals, d_lg.view(B * F, E), d_table)
+        native.bn_bwd_scatter(ids, vals, lg, d_y, eA, eB, eC, 1, d_table)     # emb_bn backward, / x = * exp(-log x), * value, scatter-add
         return d_table, d_weight, d_bias, d_ew, d_eb, d_aw, d_ab, None, None, None, None, None
 
 

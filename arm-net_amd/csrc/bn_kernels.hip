@@ -264,3 +264,52 @@ extern "C" int armnet_bn_bwd_apply_f32(int64_t N, int C, int L, const float* x, 
     a.rs = relu_scale; a.rt = relu_shift; a.out = dx;
     return launch_bn_pass<BN_BWD_APPLY>(a, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail of the sibling models' training backward (gc_arm.py:89 / afn.py:63 under autograd) in ONE pass: the embedding
+// BatchNorm's dx = coefA[f] * dy + coefC[f] * t + coefB[f] on t = exp(x) (GC-ARM) or t = log(x) (AFN), the derivative of that
+// map (exp(x) = t, or 1 / x = exp(-t)), the value scale of the lookup and the scatter-add into the table gradient
+// (layers.py:20-21) — instead of armnet_bn_bwd_apply_f32 + an elementwise op + armnet_scatter_add_f32 (three passes over
+// [B,F,E] and two temporaries).  One lane per element; rows are (sample, field) pairs, channel = row mod C.
+namespace armnet {
+template <typename IdT, int MAP>
+__global__ void bn_bwd_scatter_kernel(int64_t n_rows, int C, int E, const IdT* __restrict__ ids,
+                                      const float* __restrict__ vals, const float* __restrict__ t,
+                                      const float* __restrict__ dy, const float* __restrict__ coefA,
+                                      const float* __restrict__ coefB, const float* __restrict__ coefC, int64_t nfeat,
+                                      float* __restrict__ d_table) {
+    const int64_t total = n_rows * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / E;
+        const int e = (int)(i - r * E);
+        const int f = (int)(r % C);
+        bool bad;
+        const uint32_t id = load_id_checked(ids + r, nfeat, bad);
+        if (bad) continue;                               // the forward already raised on it
+        const float tv = t[i];
+        const float dt = fmaf(coefA[f], dy[i], fmaf(coefC[f], tv, coefB[f]));
+        const float dx = MAP == 0 ? dt * tv : dt * __expf(-tv);
+        unsafeAtomicAdd(d_table + (size_t)id * E + e, dx * vals[r]);
+    }
+}
+}  // namespace armnet
+
+extern "C" int armnet_bn_bwd_scatter_f32(int64_t n_rows, int C, int E, const void* ids, int id_type, const float* vals,
+                                         const float* t, const float* dy, const float* coefA, const float* coefB,
+                                         const float* coefC, int map, int64_t nfeat, float* d_table, void* stream) {
+    if (n_rows < 0 || C <= 0 || E <= 0 || nfeat <= 0 || (map != 0 && map != 1)) return ARMNET_ERR_BAD_ARG;
+    if (n_rows == 0) return ARMNET_OK;
+    if (!ids || !vals || !t || !dy || !coefA || !coefB || !coefC || !d_table) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
+    int64_t grid = (n_rows * E + 255) / 256;
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipStream_t s = (hipStream_t)stream;
+#define ARMNET_BBS(IdT, MAP) \
+    bn_bwd_scatter_kernel<IdT, MAP><<<(int)grid, 256, 0, s>>>(n_rows, C, E, (const IdT*)ids, vals, t, dy, coefA, coefB, coefC, nfeat, d_table)
+    if (id_type == ARMNET_ID_I64) { if (map == 0) ARMNET_BBS(int64_t, 0); else ARMNET_BBS(int64_t, 1); }
+    else { if (map == 0) ARMNET_BBS(int32_t, 0); else ARMNET_BBS(int32_t, 1); }
+#undef ARMNET_BBS
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}

@@ -197,6 +197,15 @@ int armnet_fused_bwd_bn_f32(int64_t B, int F, int E, int O, float alpha, int n_i
  *                             dx = coefA * dy + coefC * x + coefB
  *   armnet_bn_bwd_apply_f32   dx elementwise (for the block's BatchNorm use armnet_fused_bwd_bn_f32 instead)
  */
+/*
+ * armnet_bn_bwd_scatter_f32 — the tail of the sibling models' training backward in one pass (round 4): rows are the
+ * (sample, field) pairs of the lookup, channel = row mod C; t = exp(x) (map 0, gc_arm.py:89) or log(x) (map 1, afn.py:63);
+ *   d_table[ids[r], e] += (coefA[f] * dy[r,e] + coefC[f] * t[r,e] + coefB[f]) * (map == 0 ? t : exp(-t)) * vals[r]
+ * = armnet_bn_bwd_apply_f32, the derivative of exp / log, and armnet_scatter_add_f32 without the two temporaries.
+ */
+int armnet_bn_bwd_scatter_f32(int64_t n_rows, int C, int E, const void* ids, int id_type, const float* vals,
+                              const float* t, const float* dy, const float* coefA, const float* coefB,
+                              const float* coefC, int map, int64_t nfeat, float* d_table, void* stream);
 int armnet_bn_stats_f32(int64_t N, int C, int L, const float* x, float* stats, void* stream);
 int armnet_bn_finalize_f32(int C, int64_t count, const float* stats, const float* x, int L,
                            const float* weight, const float* bias, float eps, float momentum,

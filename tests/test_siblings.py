@@ -255,6 +255,28 @@ def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("map_kind", [0, 1])
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_bn_bwd_scatter_is_apply_times_derivative_scattered(map_kind, idt):
+    """armnet_bn_bwd_scatter_f32 against armnet_bn_bwd_apply_f32 + the derivative of exp / log + armnet_scatter_add_f32"""
+    from armnet_hip import native
+    B, F, E, nfeat = 77, 13, 10, 211
+    g = torch.Generator().manual_seed(5 + map_kind)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(idt).to(DEV)
+    vals = torch.rand(B, F, generator=g).to(DEV)
+    x = (torch.rand(B, F, E, generator=g) * 2 + 0.05).to(DEV)
+    t = torch.exp(x) if map_kind == 0 else torch.log(x)
+    dy = torch.randn(B, F, E, generator=g).to(DEV)
+    cA, cB, cC = (torch.randn(F, generator=g).to(DEV) for _ in range(3))
+    want = torch.zeros(nfeat, E, device=DEV)
+    dt = native.bn_backward_apply(t, dy, cA, cB, cC)
+    native.scatter_add(ids, vals, (dt * t if map_kind == 0 else dt / x).view(B * F, E), want)
+    got = torch.zeros(nfeat, E, device=DEV)
+    native.bn_bwd_scatter(ids, vals, t, dy, cA, cB, cC, map_kind, got)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["gc", "afn"])
 def test_sibling_adam_steps_reduce_the_loss(kind):
     """train.py-shaped loop: Adam + per-parameter gradient clamp hooks (train.py:61-65)"""
