@@ -16,9 +16,12 @@
 // dedup = 1 — every DISTINCT id is a request (2.56 M uniform lookups of 1 M rows ask for 0.92 M rows).  Direct-address
 //   BYTE map over (owner, local) — measured (tools/ubench/route_mark.hip): 2.56 M byte stores into a 1 MB map 14 us,
 //   4-byte stores 32 us, atomicOr into a bitmap 98-124 us — then chunk sums, a one-block scan with a restart at every
-//   owner, and an emit pass that writes the slots and a position table pos[p]; perm_pad[i] = pos[p(id_i)] is the one
-//   gather left (4-byte reads from a table that fits the L2).  Requests inside a slot come out sorted by local row
-//   index (the owner-side gather walks its shard monotonically).
+//   owner, and an emit pass that writes the slots and a COMPACT position table over the map itself: the byte of a marked
+//   id becomes its rank inside its 256-id group (one wave of the emit pass) and every group gets a 4-byte base, so
+//   perm_pad[i] = o * cap + base[p >> 8] + rank[p] is one 1-byte gather from a table of nfeat bytes (L2-resident; the
+//   4-byte table it replaces was 4 MB per million rows, written and gathered at 4x the traffic) plus a 4-byte one from
+//   a table 1/64 of that.  Requests inside a slot come out sorted by local row index (the owner-side gather walks its
+//   shard monotonically).
 #include "armnet_common.h"
 
 namespace armnet {
@@ -175,8 +178,9 @@ uniq_scan_kernel(int nchunk, int cpo, int R, int64_t cap, const int* __restrict_
 // cpo loads per block, so only while an owner has few chunks (launcher: cpo <= 8192).
 template <bool SCAN_HERE>
 __global__ void __launch_bounds__(RF_TPB)
-uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restrict__ mark, const int* __restrict__ base,
-                 int32_t* __restrict__ counts, int32_t* __restrict__ send_pad, int32_t* __restrict__ pos, int32_t* overflow) {
+uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, unsigned char* __restrict__ mark, const int* __restrict__ base,
+                 int32_t* __restrict__ counts, int32_t* __restrict__ send_pad, int32_t* __restrict__ grp_base, int64_t* cap_out,
+                 int32_t* overflow) {
     __shared__ int wsum[RF_TPB / 64];
     __shared__ int bsum[2][RF_TPB / 64];
     const int chunk = blockIdx.x, o = chunk / cpo, j = chunk - o * cpo;
@@ -209,10 +213,13 @@ uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restri
         my_base = base[chunk];
         my_count = counts[o];
     }
-    // a thread owns 4 consecutive positions (one 32-bit word of the map): the position table is written as ONE 16-byte store
-    // per lane, contiguous over the wave; the slot entries of consecutive set bytes are consecutive too
+    // a thread owns 4 consecutive positions (one 32-bit word of the map), a wave one 256-id group: the word is overwritten
+    // with the four ranks inside the group (<= 255), the group's base goes to grp_base; the slot entries of consecutive set
+    // bytes are consecutive
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cap_out = cap;       // (the position gather may run as a call of its own)
     const int64_t p0 = (int64_t)chunk * RF_CHUNK + (int64_t)threadIdx.x * 4;
-    const uint32_t w = reinterpret_cast<const uint32_t*>(mark + (size_t)chunk * RF_CHUNK)[threadIdx.x];
+    uint32_t* wp = reinterpret_cast<uint32_t*>(mark + (size_t)chunk * RF_CHUNK) + threadIdx.x;
+    const uint32_t w = *wp;
     const int mine = nonzero_bytes(w);
     int incl = mine;                                                // inclusive scan inside the wave
 #pragma unroll
@@ -222,21 +229,23 @@ uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restri
     }
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    int s = my_base + incl - mine;
-    for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) s += wsum[q];
+    int gbase = my_base;                                            // requests of this owner in front of the wave's group
+    for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) gbase += wsum[q];
+    if ((threadIdx.x & 63) == 0) grp_base[(int64_t)chunk * (RF_CHUNK / 256) + (threadIdx.x >> 6)] = gbase;
+    int rk = incl - mine;                                           // rank inside the group of this thread's first byte
+    int s = gbase + rk;
     const int64_t slot0 = (int64_t)o * cap;
     const int64_t l0 = p0 - (int64_t)o * Lp;                        // local row index of this thread's first byte
-    int4 pv;
-    int* pvp = reinterpret_cast<int*>(&pv);
+    uint32_t rw = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const bool set = (w >> (8 * b)) & 1u;
-        const bool fits = s < cap;
-        if (set && fits) send_pad[slot0 + s] = (int32_t)(l0 + b);
-        pvp[b] = (int32_t)(slot0 + (fits ? s : 0));                 // (unset positions: never read)
+        if (set && s < cap) send_pad[slot0 + s] = (int32_t)(l0 + b);   // past cap: overflow (flagged with the count)
+        rw |= (uint32_t)rk << (8 * b);                              // (unset positions: never read)
         s += set ? 1 : 0;
+        rk += set ? 1 : 0;
     }
-    *reinterpret_cast<int4*>(pos + p0) = pv;
+    *wp = rw;
     // unused tail of the owner's slot: a valid row index (0), fetched and never looked at
     const int64_t used = my_count < cap ? my_count : cap;
     const int64_t tail = cap - used, per = (tail + cpo - 1) / cpo;
@@ -247,12 +256,16 @@ uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restri
 template <typename IdT>
 __global__ void __launch_bounds__(RF_TPB)
 uniq_perm_pad_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
-                     const int32_t* __restrict__ pos, int32_t* __restrict__ perm_pad) {
+                     const unsigned char* __restrict__ rank, const int32_t* __restrict__ grp_base,
+                     const int64_t* __restrict__ cap_in, int32_t* __restrict__ perm_pad) {
+    const int64_t cap = *cap_in;
     for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
         const uint64_t v = (uint64_t)(int64_t)ids[i];
         uint32_t o, l;
         om.split(v >= (uint64_t)nfeat ? 0u : (uint32_t)v, o, l);
-        perm_pad[i] = pos[(int64_t)o * Lp + l];
+        const int64_t p = (int64_t)o * Lp + l;
+        const int64_t sl = (int64_t)grp_base[p >> 8] + rank[p];
+        perm_pad[i] = (int32_t)((int64_t)o * cap + (sl < cap ? sl : 0));   // overflow: a valid row, the wrong one (step repeated)
     }
 }
 
@@ -264,7 +277,7 @@ static int64_t rf_Lp(int R, int64_t nfeat) {
 size_t shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
     if (!dedup) return 16;
     const int64_t P = (int64_t)R * rf_Lp(R, nfeat), nchunk = P / RF_CHUNK;
-    return (size_t)P /* mark */ + (size_t)P * 4 /* pos */ + (size_t)nchunk * 8 /* sums, base */ + 256;
+    return (size_t)P /* mark, then ranks */ + (size_t)(P / 256) * 4 /* group bases */ + (size_t)nchunk * 8 /* sums, base */ + 256 /* cap */;
 }
 
 // the position gather of the de-duplicating route on its own: perm_pad[i] = pos[p(id_i)] from the workspace a preceding
@@ -277,10 +290,12 @@ int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R
     const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
     const OwnerMap om = make_owner_map(R);
-    const int32_t* pos = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(ws) + P);
+    const unsigned char* rank = reinterpret_cast<const unsigned char*>(ws);
+    const int32_t* grp_base = reinterpret_cast<const int32_t*>(rank + P);
+    const int64_t* cap_in = reinterpret_cast<const int64_t*>(grp_base + P / 256 + 2 * (P / RF_CHUNK));
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
-    if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, pos, perm_pad);
-    else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, pos, perm_pad);
+    if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, rank, grp_base, cap_in, perm_pad);
+    else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, rank, grp_base, cap_in, perm_pad);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
@@ -314,9 +329,10 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
     if (n == 0) ARMNET_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * R, st));   // (otherwise the emit pass writes every count)
     unsigned char* mark = reinterpret_cast<unsigned char*>(ws);
-    int32_t* pos = reinterpret_cast<int32_t*>(mark + P);
-    int* sums = reinterpret_cast<int*>(pos + P);
+    int32_t* grp_base = reinterpret_cast<int32_t*>(mark + P);
+    int* sums = reinterpret_cast<int*>(grp_base + P / 256);
     int* base = sums + nchunk;
+    int64_t* cap_out = reinterpret_cast<int64_t*>(base + nchunk);
     ARMNET_HIP_TRY(hipMemsetAsync(mark, 0, (size_t)P, st));
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
     if (n > 0) {
@@ -328,11 +344,11 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
     ARMNET_LAUNCH_CHECK();
     const int cpo = (int)(Lp / RF_CHUNK);
     if (cpo <= 8192) {
-        uniq_emit_kernel<true><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, sums, counts, send_pad, pos, overflow);
+        uniq_emit_kernel<true><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, sums, counts, send_pad, grp_base, cap_out, overflow);
     } else {
         uniq_scan_kernel<<<1, 1024, 0, st>>>((int)nchunk, cpo, R, cap, sums, base, counts, overflow);
         ARMNET_LAUNCH_CHECK();
-        uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, base, counts, send_pad, pos, overflow);
+        uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, base, counts, send_pad, grp_base, cap_out, overflow);
     }
     ARMNET_LAUNCH_CHECK();
     if (perm_pad) return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, ws, ws_bytes, st);
