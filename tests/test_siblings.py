@@ -255,6 +255,51 @@ def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gc", "afn"])
+def test_sibling_graphed_train_step_equals_eager_steps(kind):
+    """the fused sibling training step inside armnet_hip.modules.GraphedTrainStep (one hipGraph: no host sync, no
+    allocation inside the autograd.Functions that a capture cannot replay) against the same SGD steps run eagerly"""
+    from armnet_hip.modules import GraphedTrainStep
+    from armnet_hip.siblings import AFNModel, GC_ARMModel
+    F, E, nfeat, B = 22, 16, 503, 192
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randint(0, nfeat, (B, F), generator=g).to(DEV), torch.rand(B, F, generator=g).to(DEV),
+                (torch.rand(B, generator=g) > 0.5).float().to(DEV)) for _ in range(4)]
+    lossf = torch.nn.BCEWithLogitsLoss()
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(3)
+        m = (GC_ARMModel(F, nfeat, E, 2, 1.7, 24, 1, 32, 0.0, False, 1, 16) if kind == "gc"
+             else AFNModel(F, nfeat, E, 40, 1, 32, 0.0, False, 1, 16)).to(DEV).train()
+        assert m._fused_training_ok(F)
+        opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+        losses = []
+        if graphed:
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            step = GraphedTrainStep(m, opt, lossf, *batches[0])
+            m.load_state_dict(state)
+            for st in opt.state.values():
+                st["momentum_buffer"].zero_()
+            for ids, vals, y in batches:
+                losses.append(float(step(ids, vals.clone(), y)))
+        else:
+            for ids, vals, y in batches:
+                opt.zero_grad(set_to_none=True)
+                loss = lossf(m({"id": ids, "value": vals.clone()}), y)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            continue
+        a, b = s0[k].float(), s1[k].float()
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("map_kind", [0, 1])
 @pytest.mark.parametrize("idt", [torch.int64, torch.int32])
 def test_bn_bwd_scatter_is_apply_times_derivative_scattered(map_kind, idt):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step timing (forward + backward + Adam) of the GC-ARM / AFN modules on synthetic Criteo-shaped data
-(developer tool, GPU box): the composed device path of armnet_hip/siblings.py."""
+(developer tool, GPU box): armnet_hip/siblings.py (fused block backward where the shape has a kernel), eager and as one hipGraph."""
 import os
 import sys
 import time
@@ -53,8 +53,21 @@ def main():
                     m({"id": ids, "value": vals})
                 torch.cuda.synchronize()
                 di = (time.perf_counter() - t0) / n
-            print(f"{name:28s} B={B:6d}: train step {dt * 1e3:8.2f} ms ({B / dt / 1e6:6.2f} M samples/s)   eval forward {di * 1e3:7.3f} ms "
-                  f"({B / di / 1e6:7.1f} M samples/s)")
+            # the same step replayed as one hipGraph (armnet_hip.modules.GraphedTrainStep): what the host costs at small batches
+            from armnet_hip.modules import GraphedTrainStep
+            m.train()
+            opt2 = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+            gstep = GraphedTrainStep(m, opt2, lossf, ids, vals, y)
+            for _ in range(3):
+                gstep(ids, vals, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                gstep(ids, vals, y)
+            torch.cuda.synchronize()
+            dg = (time.perf_counter() - t0) / n
+            print(f"{name:28s} B={B:6d}: train step {dt * 1e3:8.2f} ms ({B / dt / 1e6:6.2f} M samples/s), as one hipGraph {dg * 1e3:6.2f} ms "
+                  f"({B / dg / 1e6:6.2f} M)   eval forward {di * 1e3:7.3f} ms ({B / di / 1e6:7.1f} M samples/s)")
             del m, opt
 
 
