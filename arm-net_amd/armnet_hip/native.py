@@ -34,6 +34,7 @@ EXPORTS = (
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
     "armnet_linear_small_f32", "armnet_entmax_bwd_f32", "armnet_gc_fused_bwd_supported", "armnet_gc_fused_bwd_f32",
     "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32", "armnet_bn_bwd_scatter_f32",
+    "armnet_gather_map_stats_f32",
 )
 
 _lib = None
@@ -370,20 +371,39 @@ def bn_bwd_scatter(ids, vals, t, dy, coefA, coefB, coefC, map_kind, d_table):
                                                ctypes.c_int64(d_table.shape[0]), _ptr(d_table), _stream()))
 
 
-def bn_train_stats(x, weight, bias, running_mean, running_var, momentum, eps):
+def bn_train_stats(x, weight, bias, running_mean, running_var, momentum, eps, stats=None):
     """the statistics half of bn_forward_train (running statistics updated, nothing normalised): mean, rstd, scale,
-    shift of THIS batch — for a consumer that applies the affine itself (GC-ARM's fused block, siblings.py)"""
+    shift of THIS batch — for a consumer that applies the affine itself (the siblings' fused blocks, siblings.py).
+    `stats`: a [6, C] buffer whose first two rows already hold the shifted sums of x (gather_map_stats); None = run the pass"""
     _dev_f32(x, "x")
     N, C, L = _ncl(x)
     with _on(x, weight, bias, running_mean, running_var):
-        buf = torch.zeros(6, C, device=x.device, dtype=torch.float32)
         st = _stream()
         lib = load()
-        check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
+        if stats is None:
+            buf = torch.zeros(6, C, device=x.device, dtype=torch.float32)
+            check(lib.armnet_bn_stats_f32(ctypes.c_int64(N), C, L, _ptr(x), _ptr(buf), st))
+        else:
+            buf = stats
         check(lib.armnet_bn_finalize_f32(C, ctypes.c_int64(N * L), _ptr(buf), _ptr(x), L, _ptr(weight), _ptr(bias),
                                          ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
                                          _ptr(running_var), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), st))
     return buf[2], buf[3], buf[4], buf[5]
+
+
+def gather_map_stats(ids, vals, table, map_kind, id_status=None):
+    """armnet_gather_map_stats_f32: returns (out [B,F,E] = exp / log of the scaled rows, the [6, F] buffer for bn_train_stats)"""
+    _ids_ok(ids)
+    _dev_f32(vals, "vals"); _dev_f32(table, "table")
+    B, F = vals.shape
+    E = table.shape[1]
+    with _on(ids, vals, table, id_status):
+        out = torch.empty(B, F, E, device=vals.device, dtype=torch.float32)
+        buf = torch.zeros(6, F, device=vals.device, dtype=torch.float32)
+        check(load().armnet_gather_map_stats_f32(ctypes.c_int64(B), F, E, _ptr(ids), _id_type(ids), _ptr(vals), _ptr(table),
+                                                 ctypes.c_int64(table.shape[0]), int(map_kind), _ptr(out), _ptr(buf),
+                                                 _ptr(id_status), _stream()))
+    return out, buf
 
 
 def bn_backward_coef(x, dy, weight, mean, rstd, relu_scale=None, relu_shift=None):

@@ -146,12 +146,10 @@ class _GcBlockFn(torch.autograd.Function):
         dev = vals.device
         status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
         native.clamp_vals(vals)
-        x_emb = torch.empty(B, F, E, device=dev, dtype=torch.float32)
-        native.gather_scale(B * F, E, ids, vals, table.detach(), x_emb, status)
+        ex, sbuf = native.gather_map_stats(ids, vals, table.detach(), 0, status)     # exp(lookup * value) + emb_bn's batch sums
         if status is not None and int(status.item()) != 0:
             raise IndexError("index out of range in self")
-        ex = torch.exp_(x_emb)                                               # gc_arm.py:89
-        e_mean, e_rstd, e_scale, e_shift = native.bn_train_stats(ex, emb_w.detach(), emb_b.detach(), *emb_state)
+        e_mean, e_rstd, e_scale, e_shift = native.bn_train_stats(ex, emb_w.detach(), emb_b.detach(), *emb_state, stats=sbuf)
         one, zero, sc, sh = _unit_affine(dev, O)
         qf = torch.empty(O, E, device=dev, dtype=torch.float32)
         native.fold_params(native.GC_ARM, K, H, E, E, bilinear.detach().contiguous(), Q.detach().contiguous(),
@@ -203,12 +201,10 @@ class _AfnBlockFn(torch.autograd.Function):
         dev = vals.device
         status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
         native.clamp_vals(vals)
-        x_emb = torch.empty(B, F, E, device=dev, dtype=torch.float32)
-        native.gather_scale(B * F, E, ids, vals, table.detach(), x_emb, status)
+        lg, sbuf = native.gather_map_stats(ids, vals, table.detach(), 1, status)     # log(lookup * value) + emb_bn's batch sums
         if status is not None and int(status.item()) != 0:
             raise IndexError("index out of range in self")
-        lg = torch.log_(x_emb)                                               # afn.py:63
-        l_mean, l_rstd, l_scale, l_shift = native.bn_train_stats(lg, emb_w.detach(), emb_b.detach(), *emb_state)
+        l_mean, l_rstd, l_scale, l_shift = native.bn_train_stats(lg, emb_w.detach(), emb_b.detach(), *emb_state, stats=sbuf)
         one, zero, _, _ = _unit_affine(dev, O)
         wc = weight.detach().contiguous()
         z = torch.empty(B, O, E, device=dev, dtype=torch.float32)

@@ -313,3 +313,98 @@ extern "C" int armnet_bn_bwd_scatter_f32(int64_t n_rows, int C, int E, const voi
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The head of the sibling models' training forward in ONE pass (gc_arm.py:87-89 / afn.py:61-63): lookup * value, the
+// map in front of the embedding BatchNorm (exp for GC-ARM, log for AFN) written to out [B,F,E], and that BatchNorm's
+// shifted batch sums per field (armnet_bn_stats_f32's: shift k[f] = out[0, f, 0]) — instead of armnet_gather_scale_f32 +
+// an elementwise op + armnet_bn_stats_f32 (three passes over [B,F,E]).  Skeleton of bn_pass_kernel: a thread owns one
+// inner position (field, e) and a range of samples; 16 lanes share a table row (64-byte runs).
+namespace armnet {
+template <typename IdT, int MAP>
+__global__ void __launch_bounds__(BN_TPB)
+gather_map_stats_kernel(int64_t B, int F, int E, const IdT* __restrict__ ids, const float* __restrict__ vals,
+                        const float* __restrict__ table, int64_t nfeat, float* __restrict__ out, float* __restrict__ sums,
+                        int32_t* id_status, int rows_per_block) {
+    extern __shared__ float acc[];                       // [2F]
+    for (int i = threadIdx.x; i < 2 * F; i += BN_TPB) acc[i] = 0.f;
+    __syncthreads();
+    const int CL = F * E;
+    const int i = blockIdx.y * BN_TPB + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t n1 = n0 + rows_per_block;
+    if (n1 > B) n1 = B;
+    auto map = [](float x) -> float { return MAP == 0 ? expf(x) : logf(x); };
+    if (i < CL) {
+        const int f = i / E, e = i - f * E;
+        bool bad0;
+        const uint32_t id0 = load_id_checked(ids + f, nfeat, bad0);
+        const float pivot = map(table[(size_t)id0 * E] * vals[f]);                   // = out[0, f, 0]
+        float s1 = 0.f, s2 = 0.f;
+        bool any_bad = false;
+        constexpr int U = 8;
+        for (int64_t n = n0; n < n1; n += U) {
+            uint32_t id[U];
+            float v[U], t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = (n + u < n1 ? n + u : n1 - 1) * F + f;
+                bool bad;
+                id[u] = load_id_checked(ids + r, nfeat, bad);
+                any_bad |= bad;
+                v[u] = vals[r];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = table[(size_t)id[u] * E + e];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (n + u < n1) {
+                    const float xv = map(t[u] * v[u]);
+                    out[(size_t)(n + u) * CL + i] = xv;
+                    const float d = xv - pivot;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            }
+        }
+        if (any_bad && id_status) atomicOr(id_status, 1);
+        atomicAdd(&acc[f], s1);
+        atomicAdd(&acc[F + f], s2);
+    }
+    __syncthreads();
+    const int c_lo = (blockIdx.y * BN_TPB) / E;
+    int c_hi = (blockIdx.y * BN_TPB + BN_TPB - 1) / E;
+    if (c_hi >= F) c_hi = F - 1;
+    for (int c = c_lo + threadIdx.x; c <= c_hi; c += BN_TPB) {
+        unsafeAtomicAdd(sums + c, acc[c]);
+        unsafeAtomicAdd(sums + F + c, acc[F + c]);
+    }
+}
+}  // namespace armnet
+
+extern "C" int armnet_gather_map_stats_f32(int64_t B, int F, int E, const void* ids, int id_type, const float* vals,
+                                           const float* table, int64_t nfeat, int map, float* out, float* stats,
+                                           int32_t* id_status, void* stream) {
+    if (B < 0 || F <= 0 || E <= 0 || nfeat <= 0 || (map != 0 && map != 1)) return ARMNET_ERR_BAD_ARG;
+    if (B == 0) return ARMNET_OK;
+    if (!ids || !vals || !table || !out || !stats) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (nfeat >= ((int64_t)1 << 31) || (int64_t)F * E >= ((int64_t)1 << 24)) return ARMNET_ERR_UNSUPPORTED;
+    const int CL = F * E, ny = (CL + BN_TPB - 1) / BN_TPB;
+    int64_t nx = 2048 / ny;
+    if (nx < 1) nx = 1;
+    int64_t rpb = (B + nx - 1) / nx;
+    if (rpb < 16) rpb = 16;
+    nx = (B + rpb - 1) / rpb;
+    const size_t lds = (size_t)2 * F * sizeof(float);
+    if (lds > 64 * 1024) return ARMNET_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nx, (unsigned)ny);
+#define ARMNET_GMS(IdT, MAP) \
+    gather_map_stats_kernel<IdT, MAP><<<grid, BN_TPB, lds, s>>>(B, F, E, (const IdT*)ids, vals, table, nfeat, out, stats, id_status, (int)rpb)
+    if (id_type == ARMNET_ID_I64) { if (map == 0) ARMNET_GMS(int64_t, 0); else ARMNET_GMS(int64_t, 1); }
+    else { if (map == 0) ARMNET_GMS(int32_t, 0); else ARMNET_GMS(int32_t, 1); }
+#undef ARMNET_GMS
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}

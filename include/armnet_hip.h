@@ -198,6 +198,16 @@ int armnet_fused_bwd_bn_f32(int64_t B, int F, int E, int O, float alpha, int n_i
  *   armnet_bn_bwd_apply_f32   dx elementwise (for the block's BatchNorm use armnet_fused_bwd_bn_f32 instead)
  */
 /*
+ * armnet_gather_map_stats_f32 — the head of the sibling models' training forward in one pass (round 4):
+ *   out[b,f,:] = map(table[ids[b,f], :] * vals[b,f]),  map = exp (0, gc_arm.py:87-89) or log (1, afn.py:61-63; table clipped);
+ *   stats[f] += sum (out - k_f), stats[F + f] += sum (out - k_f)^2 with k_f = out[0, f, 0]  — exactly what
+ *   armnet_bn_stats_f32 would add for out viewed as [B, F, E] (caller zero-initialises stats[2F], then armnet_bn_finalize_f32).
+ *   vals must already be clamped (armnet_clamp_vals_f32); *id_status |= 1 for an id outside [0, nfeat) (it reads row 0).
+ */
+int armnet_gather_map_stats_f32(int64_t B, int F, int E, const void* ids, int id_type, const float* vals,
+                                const float* table, int64_t nfeat, int map, float* out, float* stats,
+                                int32_t* id_status, void* stream);
+/*
  * armnet_bn_bwd_scatter_f32 — the tail of the sibling models' training backward in one pass (round 4): rows are the
  * (sample, field) pairs of the lookup, channel = row mod C; t = exp(x) (map 0, gc_arm.py:89) or log(x) (map 1, afn.py:63);
  *   d_table[ids[r], e] += (coefA[f] * dy[r,e] + coefC[f] * t[r,e] + coefB[f]) * (map == 0 ? t : exp(-t)) * vals[r]

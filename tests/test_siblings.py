@@ -302,6 +302,40 @@ def test_sibling_graphed_train_step_equals_eager_steps(kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("map_kind", [0, 1])
 @pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+@pytest.mark.parametrize("B,F,E", [(77, 13, 10), (1, 3, 4), (4099, 39, 16), (300, 48, 32)])
+def test_gather_map_stats_is_gather_then_map_then_bn_stats(map_kind, idt, B, F, E):
+    """armnet_gather_map_stats_f32 against armnet_gather_scale_f32 + torch.exp / log + armnet_bn_stats_f32 (through the
+    finalised mean / rstd: the shifted sums themselves depend on the pivot only through rounding)"""
+    from armnet_hip import native
+    nfeat = 211
+    g = torch.Generator().manual_seed(B + map_kind)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(idt).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+    table = (torch.rand(nfeat, E, generator=g) * 0.8 + 1e-2).to(DEV)
+    w, b = torch.rand(F, generator=g).to(DEV) + 0.5, torch.randn(F, generator=g).to(DEV)
+    x = torch.empty(B, F, E, device=DEV)
+    native.gather_scale(B * F, E, ids, vals, table, x, None)
+    want = torch.exp(x) if map_kind == 0 else torch.log(x)
+    rm0, rv0 = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    ref = native.bn_train_stats(want, w, b, rm0, rv0, 0.1, 1e-5)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out, sbuf = native.gather_map_stats(ids, vals, table, map_kind, status)
+    got = native.bn_train_stats(out, w, b, rm1, rv1, 0.1, 1e-5, stats=sbuf)
+    assert int(status.item()) == 0
+    torch.testing.assert_close(out, want, rtol=2e-6, atol=1e-6)
+    if B * E > 1:
+        for a, c in zip(got + (rm1, rv1), ref + (rm0, rv0)):
+            torch.testing.assert_close(a, c, rtol=3e-5, atol=3e-6)
+    bad = ids.clone()
+    bad[0, 0] = nfeat
+    native.gather_map_stats(bad, vals, table, map_kind, status)
+    assert int(status.item()) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("map_kind", [0, 1])
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
 def test_bn_bwd_scatter_is_apply_times_derivative_scattered(map_kind, idt):
     """armnet_bn_bwd_scatter_f32 against armnet_bn_bwd_apply_f32 + the derivative of exp / log + armnet_scatter_add_f32"""
     from armnet_hip import native
