@@ -255,6 +255,27 @@ def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
 
 
 @pytest.mark.gpu
+def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
+    """armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32 on ~230 of the shapes of tools/sibling_bwd_scan.py (7 239 there:
+    every nfield 1..48, nemb 4..32, one / two neuron slices, every solver) against the backward written out in float64"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "sibling_bwd_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sibling_bwd_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    g = torch.Generator().manual_seed(0)
+    n = 0
+    for F in (1, 2, 3, 4, 5, 9, 16, 17, 22, 31, 39, 40, 43, 48):
+        for E in (4, 7, 10, 16, 17, 31, 32):
+            if (F + E) % 2:
+                continue
+            for O, kind, alpha in ((1, "gc", 2.0), (20, "gc", 1.7), (70, "gc", 1.0), (70, "gc", 1.5), (20, "afn", 1.0), (70, "afn", 1.0)):
+                assert scan.case(kind, F, E, O, alpha, 37, g) == 0.0, (kind, F, E, O, alpha)
+                n += 1
+    assert n > 200
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["gc", "afn"])
 def test_sibling_graphed_train_step_equals_eager_steps(kind):
     """the fused sibling training step inside armnet_hip.modules.GraphedTrainStep (one hipGraph: no host sync, no
