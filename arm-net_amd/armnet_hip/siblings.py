@@ -9,12 +9,16 @@ the element-wise maps around the contraction:
     AFN (models/afn.py)        weights = afn.weight (fixed); contraction over emb_bn(log(x)); bias, outer exp
 
 Eval-mode inference runs on armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head.  Training
-(train.py:108-114 with --model gc_arm / afn; round 3) runs the reference's op chain on the device with autograd: HIP
-kernels for the lookup and its scatter-add gradient (armnet_gather_scale_f32 / armnet_scatter_add_f32), the in-place
-clamp / clip, the sparse map (armnet_entmax_f32, backward = utils/entmax.py:70-80 on the saved output), every
-training-mode BatchNorm1d (bn_kernels.hip) and the head's Linear + BatchNorm + ReLU passes; the three small contractions
-(gates, interaction, AFN's Linear over the fields) go to hipBLASLt through torch.  A fused backward like the ARM block's
-(armnet_fused_bwd_f32) is not built for the siblings."""
+(train.py:108-114 with --model gc_arm / afn):
+  * round 4, nemb <= 32 and nfield <= 48 — the block as ONE autograd.Function around the fused kernels (_GcBlockFn /
+    _AfnBlockFn): armnet_gather_map_stats_f32 (lookup * value, exp / log, emb_bn's batch sums), the fused forward with this
+    batch's emb_bn affine, HIP BatchNorm passes for the block's BatchNorm, armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32
+    on the matrix cores, emb_bn's backward sums and armnet_bn_bwd_scatter_f32.  No [B, K*H, F] tensor is written.
+  * otherwise (round 3) — the reference's op chain on the device with autograd: HIP kernels for the lookup and its
+    scatter-add gradient (armnet_gather_scale_f32 / armnet_scatter_add_f32), the in-place clamp / clip, the sparse map
+    (armnet_entmax_f32, backward armnet_entmax_bwd_f32 = utils/entmax.py:70-80 on the saved output), every training-mode
+    BatchNorm1d (bn_kernels.hip); the small contractions go to hipBLASLt through torch (split-K weight gradients).
+The head's Linear + BatchNorm + ReLU passes are shared with ARM-Net (modules.py)."""
 import torch
 import torch.nn as nn
 
