@@ -5,6 +5,9 @@ data_loader.py:12-73).
 y Float[N], nsamples) and its skip-malformed-lines behaviour, but the text is parsed by
 csrc/libsvm_reader.cpp (mmap + OpenMP) instead of a Python loop over lines.
 ``libsvm_dataloader(args)`` returns the same three torch DataLoaders the reference's train.py expects.
+``LibsvmDataset(..., cache=True | path)`` keeps the parsed split beside the text as ONE binary file (header + the three
+arrays, memory-mapped back: SURVEY.md §8f-3's "binary pre-tokenised format"); a cache whose
+header does not match the text file's size / mtime / nfields is ignored and rewritten.
 ``DeviceLoader`` is the MI355X-first alternative: the whole split lives in HBM (Criteo's 45 M x 39 samples
 are 21 GB of the 288 GB) and batches are slices — no worker processes, no pinned staging, no per-batch H2D.
 """
@@ -12,6 +15,7 @@ import ctypes
 import glob
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
 
@@ -30,10 +34,70 @@ def _lib():
     return _io
 
 
-class LibsvmDataset(Dataset):
-    """Dataset loader for the libsvm text format (reference: data_loader.py:12-55)."""
+_CACHE_MAGIC = b"ARMNETDS"
+_CACHE_VERSION = 1
 
-    def __init__(self, fname, nfields, nthreads=0):
+
+def _cache_header(fname, nfields, nlines, nsamples, nskipped):
+    st = os.stat(fname)
+    return np.array([_CACHE_VERSION, nfields, nlines, nsamples, nskipped, st.st_size, st.st_mtime_ns], dtype=np.int64)
+
+
+def _cache_read(cache, fname, nfields):
+    """(feat_id, feat_value, y, nsamples, nskipped) from a cache written for exactly this text file, or None"""
+    try:
+        with open(cache, "rb") as f:
+            if f.read(8) != _CACHE_MAGIC:
+                return None
+            h = np.fromfile(f, dtype=np.int64, count=7)
+            st = os.stat(fname)
+            if h.size != 7 or h[0] != _CACHE_VERSION or h[1] != nfields or h[5] != st.st_size or h[6] != st.st_mtime_ns:
+                return None
+            rows = max(int(h[2]), 1)
+            off = 8 + 7 * 8
+            need = off + rows * nfields * 12 + rows * 4
+            if os.fstat(f.fileno()).st_size != need:
+                return None                                     # truncated / foreign file
+        # copy-on-write maps: construction is O(1), pages come in as they are touched (a DeviceLoader streams them once),
+        # and the tensors stay writable like the parsed ones without ever changing the file
+        ids = np.memmap(cache, dtype=np.int64, mode="c", offset=off, shape=(rows, nfields))
+        vals = np.memmap(cache, dtype=np.float32, mode="c", offset=off + rows * nfields * 8, shape=(rows, nfields))
+        y = np.memmap(cache, dtype=np.float32, mode="c", offset=off + rows * nfields * 12, shape=(rows,))
+    except (OSError, ValueError):
+        return None
+    return torch.from_numpy(ids), torch.from_numpy(vals), torch.from_numpy(y), int(h[3]), int(h[4])
+
+
+def _cache_write(cache, header, feat_id, feat_value, y):
+    tmp = f"{cache}.tmp{os.getpid()}"
+    try:
+        with open(tmp, "wb") as f:
+            f.write(_CACHE_MAGIC)
+            header.tofile(f)
+            feat_id.numpy().tofile(f)
+            feat_value.numpy().tofile(f)
+            y.numpy().tofile(f)
+        os.replace(tmp, cache)                                  # readers never see a half-written cache
+    except OSError as e:
+        print(f"# binary cache {cache} not written: {e}")
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+
+
+class LibsvmDataset(Dataset):
+    """Dataset loader for the libsvm text format (reference: data_loader.py:12-55).  cache: None / False = parse the text
+    every time (the reference's behaviour); True = `<fname>.armnet.bin`; a path = that file."""
+
+    def __init__(self, fname, nfields, nthreads=0, cache=None):
+        cache_path = (f"{fname}.armnet.bin" if cache is True else cache) or None
+        if cache_path and os.path.exists(cache_path):
+            hit = _cache_read(cache_path, fname, int(nfields))
+            if hit is not None:
+                self.feat_id, self.feat_value, self.y, self.nsamples, self.nskipped = hit
+                print(f"# {self.nsamples} data samples loaded... (binary cache {cache_path})")
+                return
         lib = _lib()
         path = os.fsencode(fname)
         nlines = int(lib.armnet_libsvm_count_lines(path))
@@ -55,6 +119,9 @@ class LibsvmDataset(Dataset):
         if self.nskipped:
             print(f"{self.nskipped} line(s) of incorrect data format skipped !")
         print(f"# {self.nsamples} data samples loaded...")
+        if cache_path:
+            _cache_write(cache_path, _cache_header(fname, int(nfields), nlines, self.nsamples, self.nskipped), feat_id,
+                         feat_value, y)
 
     def __len__(self):
         return self.nsamples
@@ -68,7 +135,8 @@ def libsvm_dataloader(args):
     data_dir = args.data_dir + args.dataset
     files = [glob.glob(f"{data_dir}/{p}*libsvm")[0] for p in ("tr", "va", "te")]
     shuffle = (True, False, False)
-    return tuple(DataLoader(LibsvmDataset(f, args.nfield), batch_size=args.batch_size, shuffle=s,
+    cache = getattr(args, "binary_cache", None)       # not a reference flag: True keeps <file>.armnet.bin beside each split
+    return tuple(DataLoader(LibsvmDataset(f, args.nfield, cache=cache), batch_size=args.batch_size, shuffle=s,
                             num_workers=args.workers, pin_memory=True) for f, s in zip(files, shuffle))
 
 
