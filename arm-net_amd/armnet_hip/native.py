@@ -34,7 +34,8 @@ EXPORTS = (
     "armnet_shard_route_fixed_ws_bytes", "armnet_shard_route_fixed", "armnet_shard_route_fixed_perm",
     "armnet_linear_small_f32", "armnet_entmax_bwd_f32", "armnet_gc_fused_bwd_supported", "armnet_gc_fused_bwd_f32",
     "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32", "armnet_bn_bwd_scatter_f32",
-    "armnet_gather_map_stats_f32",
+    "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
+    "armnet_shard_route_fixed_epoch",
 )
 
 _lib = None
@@ -557,18 +558,35 @@ def shard_route_fixed_ws_bytes(R, nfeat, dedup):
     return int(load().armnet_shard_route_fixed_ws_bytes(int(R), ctypes.c_int64(nfeat), int(bool(dedup))))
 
 
-def shard_route_fixed(n, ids, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, workspace=None, id_status=None):
-    """routing of the fixed-capacity protocol in one call: send_pad [R*cap], perm_pad [n], counts [R], overflow flag"""
+def shard_route_fixed(n, ids, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, workspace=None, id_status=None,
+                      epoch=0):
+    """routing of the fixed-capacity protocol in one call: send_pad [R*cap], perm_pad [n], counts [R], overflow flag.
+    epoch (dedup only): 0 = the mark map is zeroed by the call; 2..255 = caller-managed mark epoch, no fill
+    (armnet_shard_route_fixed_epoch: valid after a call with epoch 0 or a smaller epoch on the same workspace)"""
     _ids_ok(ids)
     _i32_ok(send_pad=send_pad, counts=counts, overflow=overflow)
     if perm_pad is not None:                 # None (dedup only): the position gather is left to shard_route_fixed_perm
         _i32_ok(perm_pad=perm_pad)
     with _on(ids, send_pad, perm_pad, counts, overflow, workspace, id_status):
-        check(load().armnet_shard_route_fixed(
+        check(load().armnet_shard_route_fixed_epoch(
             ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), ctypes.c_int64(cap),
             int(bool(dedup)), _ptr(send_pad), _ptr(perm_pad), _ptr(counts), _ptr(overflow), _ptr(id_status),
             _ptr(workspace), ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
-            _stream()))
+            int(epoch), _stream()))
+
+
+def shard_gather_perm(idx, table, out, ids, R, nfeat, perm_pad, workspace):
+    """armnet_shard_gather_perm_f32: out[j] = table[idx[j]] and perm_pad[i] = position of ids[i] (workspace of a preceding
+    shard_route_fixed(dedup=True, perm_pad=None)) in one launch"""
+    _ids_ok(ids)
+    _dev_f32(table, "table"); _dev_f32(out, "out")
+    if idx.dtype != torch.int32 or perm_pad.dtype != torch.int32:
+        raise ArmnetNativeError("shard_gather_perm: idx and perm_pad must be int32")
+    with _on(idx, table, out, ids, perm_pad, workspace):
+        check(load().armnet_shard_gather_perm_f32(ctypes.c_int64(idx.numel()), table.shape[1], _ptr(idx), _ptr(table),
+                                                  ctypes.c_int64(table.shape[0]), _ptr(out), ctypes.c_int64(ids.numel()),
+                                                  _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), _ptr(perm_pad),
+                                                  _ptr(workspace), ctypes.c_int64(workspace.numel()), _stream()))
 
 
 def shard_route_fixed_perm(n, ids, R, nfeat, perm_pad, workspace):

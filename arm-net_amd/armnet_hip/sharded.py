@@ -46,6 +46,7 @@ class HipShardOps:
         self._ws = {}            # workspace of the de-duplicating route, reused across steps: one per (device, stream),
                                  # so that steps in flight on different streams never share it
         self.overlap_perm = True # de-duplicating fixed route: the position gather on a side stream (see route_fixed)
+        self.mark_epochs = True  # de-duplicating fixed route: the byte map is zeroed once per 255 steps (False: every step)
 
     def route(self, ids_flat, R, nfeat, dedup=False, id_status=None):
         """-> counts [R], send_local [>= sum(counts)], perm [n].  With dedup every distinct id is sent once.
@@ -82,7 +83,15 @@ class HipShardOps:
         native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
         return send_pad, perm_pad
 
-    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, defer_perm=False):
+    def gather_perm(self, local_idx, table_local, pending):
+        """the owner-side gather AND the position gather a route_fixed(..., perm_with_gather=True) left pending, as one launch
+        (armnet_shard_gather_perm_f32): -> rows [len(local_idx), E]; pending's perm_pad is filled in order on this stream"""
+        ids_flat, R, nfeat, perm_pad, ws = pending
+        out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
+        native.shard_gather_perm(local_idx, table_local, out, ids_flat, R, nfeat, perm_pad, ws)
+        return out
+
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, defer_perm=False, perm_with_gather=False):
         """-> send_pad [R*cap], perm_pad [n] (armnet_shard_route_fixed: routing of the fixed-capacity protocol in one call —
         one kernel without de-duplication; byte-map mark + chunk sums + emit, then one position gather, with it).
         overflow (int32[1]) |= 1 if a slot is too small.
@@ -106,10 +115,26 @@ class HipShardOps:
         st = self._ws.get(key)
         if st is None or st["ws"].numel() < need:
             st = self._ws[key] = {"ws": torch.empty(need, device=dev, dtype=torch.uint8), "side": torch.cuda.Stream(device=dev),
-                                  "busy": None}
+                                  "busy": None, "epoch": 0, "shape": None}
         if st["busy"] is not None:
             cur.wait_event(st["busy"])                 # the previous step's position gather still reads the workspace
-        native.shard_route_fixed(n, ids_flat, R, nfeat, cap, True, send_pad, None, counts, overflow, st["ws"], id_status)
+        # mark epoch of the byte map: 0 (the call zeroes the map, marks are 1), then 2, 3, .., 255 without a fill, then 0 again;
+        # a workspace that is new, or whose layout (R, nfeat) changed, starts over
+        if st["shape"] != (R, nfeat):
+            st["shape"], st["epoch"] = (R, nfeat), 0
+        if not self.mark_epochs or torch.cuda.is_current_stream_capturing():
+            # (a captured step replays its kernel arguments: every replay would mark with the same epoch)
+            epoch, st["epoch"] = 0, 0
+        else:
+            epoch = st["epoch"]
+            st["epoch"] = 2 if epoch == 0 else (epoch + 1 if epoch < 255 else 0)
+        native.shard_route_fixed(n, ids_flat, R, nfeat, cap, True, send_pad, None, counts, overflow, st["ws"], id_status,
+                                 epoch=epoch)
+        if perm_with_gather:
+            # the position gather rides in the owner-side gather's launch (gather_perm), in order on this stream
+            st["busy"] = None
+            perm_pad._armnet_pending = (ids_flat, R, nfeat, perm_pad, st["ws"])
+            return send_pad, perm_pad
         if not (defer_perm and self.overlap_perm):
             native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"])
             st["busy"] = None
@@ -151,6 +176,7 @@ class RowShardedTable:
                                   # whenever `table_local` is assigned (the property below)
         self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
         self.fused_route = True   # fixed protocol: armnet_shard_route_fixed (False: route + pad_route, the round-3 kernels)
+        self.gather_with_perm = True   # de-dup, no side stream: position gather inside the owner-side gather's launch
         self.slot_lookups = None  # lookups per step the slots of the fixed protocol are sized for; None: agreed over the
                                   # ranks (MAX) by the first lookup — see _agreed_lookups
         self.table_local = table_local
@@ -286,6 +312,10 @@ class RowShardedTable:
             if defer_perm and R > 1 and isinstance(self.ops, HipShardOps):
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status,
                                                           defer_perm=True)
+            elif dedup and self.gather_with_perm and isinstance(self.ops, HipShardOps):
+                # in order on one stream: the position gather shares the owner-side gather's launch (their blocks overlap)
+                send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status,
+                                                          perm_with_gather=True)
             else:
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status)
         else:
@@ -299,11 +329,16 @@ class RowShardedTable:
                 counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
             send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
         E = self.table_local.shape[1]
+        pending = getattr(perm_pad, "_armnet_pending", None)
+        gather = (lambda idx: self.ops.gather_perm(idx, self.table_local, pending)) if pending is not None else \
+                 (lambda idx: self.ops.gather(idx, self.table_local))
+        if pending is not None:
+            del perm_pad._armnet_pending
         if R == 1 and not dist.is_initialized():
-            return self.ops.gather(send_pad, self.table_local), perm_pad
+            return gather(send_pad), perm_pad
         recv_idx = torch.empty(R * cap, device=dev, dtype=torch.int32)
         self._all_to_all(recv_idx, send_pad, None, None)
-        rows_out = self.ops.gather(recv_idx, self.table_local)
+        rows_out = gather(recv_idx)
         rows_in = torch.empty(R * cap, E, device=dev, dtype=torch.float32)
         self._all_to_all(rows_in, rows_out, None, None)
         return rows_in, perm_pad

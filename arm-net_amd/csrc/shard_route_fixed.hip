@@ -111,24 +111,28 @@ route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t 
 template <typename IdT>
 __global__ void __launch_bounds__(RF_TPB)
 uniq_mark_bytes_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
-                       unsigned char* __restrict__ mark, int32_t* id_status) {
+                       unsigned char* __restrict__ mark, unsigned char epoch, int32_t* id_status) {
     for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
         uint32_t o, l;
         om.split(checked_id(ids, i, nfeat, id_status), o, l);
-        mark[(int64_t)o * Lp + l] = 1;
+        mark[(int64_t)o * Lp + l] = epoch;
     }
 }
 
-__device__ __forceinline__ int nonzero_bytes(uint32_t w) {
-    // one bit per non-zero byte (the map only ever holds 0 / 1)
-    return __popc(w & 0x01010101u);
+// The map holds the EPOCH of the last step that marked a position (1..255; 0 = never): a step's marks are the bytes equal
+// to its epoch, so the map is zeroed once per 255 steps instead of once per step (a 1 MB fill is a launch like any other).
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t e4) {
+    // 0x01 in every byte of w that equals the epoch (e4 = epoch replicated into 4 bytes)
+    const uint32_t x = w ^ e4;                                      // zero bytes <=> equal
+    const uint32_t nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;      // bit 7 of a byte set <=> byte non-zero
+    return (~nz >> 7) & 0x01010101u;
 }
 
 __global__ void __launch_bounds__(RF_TPB)
-uniq_chunk_sums_kernel(const unsigned char* __restrict__ mark, int* __restrict__ sums) {
+uniq_chunk_sums_kernel(const unsigned char* __restrict__ mark, uint32_t e4, int* __restrict__ sums) {
     __shared__ int wsum[RF_TPB / 64];
     const uint32_t v = reinterpret_cast<const uint32_t*>(mark + (size_t)blockIdx.x * RF_CHUNK)[threadIdx.x];
-    int c = nonzero_bytes(v);
+    int c = __popc(eq_bytes(v, e4));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -178,9 +182,9 @@ uniq_scan_kernel(int nchunk, int cpo, int R, int64_t cap, const int* __restrict_
 // cpo loads per block, so only while an owner has few chunks (launcher: cpo <= 8192).
 template <bool SCAN_HERE>
 __global__ void __launch_bounds__(RF_TPB)
-uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, unsigned char* __restrict__ mark, const int* __restrict__ base,
-                 int32_t* __restrict__ counts, int32_t* __restrict__ send_pad, int32_t* __restrict__ grp_base, int64_t* cap_out,
-                 int32_t* overflow) {
+uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restrict__ mark, uint32_t e4,
+                 unsigned char* __restrict__ rank, const int* __restrict__ base, int32_t* __restrict__ counts,
+                 int32_t* __restrict__ send_pad, int32_t* __restrict__ grp_base, int64_t* cap_out, int32_t* overflow) {
     __shared__ int wsum[RF_TPB / 64];
     __shared__ int bsum[2][RF_TPB / 64];
     const int chunk = blockIdx.x, o = chunk / cpo, j = chunk - o * cpo;
@@ -213,14 +217,14 @@ uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, unsigned char* __restrict__ m
         my_base = base[chunk];
         my_count = counts[o];
     }
-    // a thread owns 4 consecutive positions (one 32-bit word of the map), a wave one 256-id group: the word is overwritten
-    // with the four ranks inside the group (<= 255), the group's base goes to grp_base; the slot entries of consecutive set
-    // bytes are consecutive
+    // a thread owns 4 consecutive positions (one 32-bit word of the map), a wave one 256-id group: the four ranks inside
+    // the group (<= 255) go to the rank table as one word, the group's base to grp_base; the slot entries of consecutive
+    // set bytes are consecutive
     if (blockIdx.x == 0 && threadIdx.x == 0) *cap_out = cap;       // (the position gather may run as a call of its own)
     const int64_t p0 = (int64_t)chunk * RF_CHUNK + (int64_t)threadIdx.x * 4;
-    uint32_t* wp = reinterpret_cast<uint32_t*>(mark + (size_t)chunk * RF_CHUNK) + threadIdx.x;
-    const uint32_t w = *wp;
-    const int mine = nonzero_bytes(w);
+    uint32_t* wp = reinterpret_cast<uint32_t*>(rank + (size_t)chunk * RF_CHUNK) + threadIdx.x;
+    const uint32_t w = eq_bytes(reinterpret_cast<const uint32_t*>(mark + (size_t)chunk * RF_CHUNK)[threadIdx.x], e4);
+    const int mine = __popc(w);
     int incl = mine;                                                // inclusive scan inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -269,6 +273,55 @@ uniq_perm_pad_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_
     }
 }
 
+// The owner-side gather of the request list and the position gather of the de-duplicating route as ONE launch: the two
+// only depend on the emit pass, are needed only by the fused block, and bound differently (the row gather by bytes, the
+// position gather by the address unit: one cache line per lane), so their blocks — interleaved in the grid — overlap
+// instead of queueing (one rank, headline step: 23 + 18 us in a row -> see profiles/r04_routing_fixed_protocol.txt).
+//   rows:  out[j, :] = table[idx[j], :]   in W-float chunks (W = 4 / 2 / 1 by the divisibility of nemb)
+//   perm:  uniq_perm_pad_kernel
+template <typename IdT, int W>
+__global__ void __launch_bounds__(RF_TPB)
+gather_rows_perm_kernel(int64_t n_rows, int EW, const int32_t* __restrict__ idx, const float* __restrict__ table,
+                        int64_t table_rows, float* __restrict__ out, int gather_blocks, int perm_blocks, int64_t n,
+                        const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+                        const unsigned char* __restrict__ rank, const int32_t* __restrict__ grp_base,
+                        const int64_t* __restrict__ cap_in, int32_t* __restrict__ perm_pad) {
+    // block roles interleaved while both kinds last: even -> rows, odd -> positions
+    const int b = blockIdx.x, paired = 2 * (gather_blocks < perm_blocks ? gather_blocks : perm_blocks);
+    bool rows_role;
+    int role_idx;
+    if (b < paired) {
+        rows_role = (b & 1) == 0;
+        role_idx = b >> 1;
+    } else {
+        rows_role = gather_blocks > perm_blocks;
+        role_idx = paired / 2 + (b - paired);
+    }
+    if (rows_role) {
+        typedef float vecW __attribute__((ext_vector_type(W)));
+        const int64_t total = n_rows * EW;
+        const vecW* __restrict__ src = reinterpret_cast<const vecW*>(table);
+        vecW* __restrict__ dst = reinterpret_cast<vecW*>(out);
+        for (int64_t i = (int64_t)role_idx * RF_TPB + threadIdx.x; i < total; i += (int64_t)gather_blocks * RF_TPB) {
+            const int64_t r = i / EW;
+            const int c = (int)(i - r * EW);
+            const uint32_t row = (uint32_t)idx[r];
+            if constexpr (W == 1) dst[i] = src[(size_t)(row < (uint64_t)table_rows ? row : 0u) * EW + c];
+            else dst[i] = src[(size_t)(row < (uint64_t)table_rows ? row : 0u) * EW + c];
+        }
+    } else {
+        const int64_t cap = *cap_in;
+        for (int64_t i = (int64_t)role_idx * RF_TPB + threadIdx.x; i < n; i += (int64_t)perm_blocks * RF_TPB) {
+            const uint64_t v = (uint64_t)(int64_t)ids[i];
+            uint32_t o, l;
+            om.split(v >= (uint64_t)nfeat ? 0u : (uint32_t)v, o, l);
+            const int64_t p = (int64_t)o * Lp + l;
+            const int64_t sl = (int64_t)grp_base[p >> 8] + rank[p];
+            perm_pad[i] = (int32_t)((int64_t)o * cap + (sl < cap ? sl : 0));
+        }
+    }
+}
+
 static int64_t rf_Lp(int R, int64_t nfeat) {
     const int64_t L = (nfeat + R - 1) / R;
     return (L + RF_CHUNK - 1) / RF_CHUNK * RF_CHUNK;
@@ -277,7 +330,7 @@ static int64_t rf_Lp(int R, int64_t nfeat) {
 size_t shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
     if (!dedup) return 16;
     const int64_t P = (int64_t)R * rf_Lp(R, nfeat), nchunk = P / RF_CHUNK;
-    return (size_t)P /* mark, then ranks */ + (size_t)(P / 256) * 4 /* group bases */ + (size_t)nchunk * 8 /* sums, base */ + 256 /* cap */;
+    return (size_t)P /* mark epochs */ + (size_t)P /* ranks */ + (size_t)(P / 256) * 4 /* group bases */ + (size_t)nchunk * 8 /* sums, base */ + 256 /* cap */;
 }
 
 // the position gather of the de-duplicating route on its own: perm_pad[i] = pos[p(id_i)] from the workspace a preceding
@@ -290,7 +343,7 @@ int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R
     const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
     const OwnerMap om = make_owner_map(R);
-    const unsigned char* rank = reinterpret_cast<const unsigned char*>(ws);
+    const unsigned char* rank = reinterpret_cast<const unsigned char*>(ws) + P;
     const int32_t* grp_base = reinterpret_cast<const int32_t*>(rank + P);
     const int64_t* cap_in = reinterpret_cast<const int64_t*>(grp_base + P / 256 + 2 * (P / RF_CHUNK));
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
@@ -300,9 +353,39 @@ int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R
     return ARMNET_OK;
 }
 
+int launch_shard_gather_perm(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows, float* out,
+                             int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad, const void* ws,
+                             size_t ws_bytes, hipStream_t st) {
+    if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if (n_rows == 0 && n == 0) return ARMNET_OK;
+    const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
+    if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
+    const OwnerMap om = make_owner_map(R);
+    const unsigned char* rank = reinterpret_cast<const unsigned char*>(ws) + P;
+    const int32_t* grp_base = reinterpret_cast<const int32_t*>(rank + P);
+    const int64_t* cap_in = reinterpret_cast<const int64_t*>(grp_base + P / 256 + 2 * (P / RF_CHUNK));
+    const bool a16 = ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0), a8 = ((uintptr_t)table % 8 == 0) && ((uintptr_t)out % 8 == 0);
+    const int W = (E % 4 == 0 && a16) ? 4 : (E % 2 == 0 && a8) ? 2 : 1;
+    const int EW = E / W;
+    const int64_t chunks = n_rows * EW;
+    // ~4 chunks per thread for the rows, one lookup per thread and trip for the positions (as the stand-alone kernels)
+    int gb = (int)((chunks + RF_TPB * 4 - 1) / (RF_TPB * 4) < 4096 ? (chunks + RF_TPB * 4 - 1) / (RF_TPB * 4) : 4096);
+    int pb = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
+    if (n_rows > 0 && gb < 1) gb = 1;
+    if (n > 0 && pb < 1) pb = 1;
+#define ARMNET_GRP(IdT, W_) \
+    gather_rows_perm_kernel<IdT, W_><<<gb + pb, RF_TPB, 0, st>>>(n_rows, EW, idx, table, table_rows, out, gb, pb, n, (const IdT*)ids, \
+                                                              om, nfeat, Lp, rank, grp_base, cap_in, perm_pad)
+    if (id_type == ARMNET_ID_I64) { if (W == 4) ARMNET_GRP(int64_t, 4); else if (W == 2) ARMNET_GRP(int64_t, 2); else ARMNET_GRP(int64_t, 1); }
+    else { if (W == 4) ARMNET_GRP(int32_t, 4); else if (W == 2) ARMNET_GRP(int32_t, 2); else ARMNET_GRP(int32_t, 1); }
+#undef ARMNET_GRP
+    ARMNET_LAUNCH_CHECK();
+    return ARMNET_OK;
+}
+
 int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow, int32_t* id_status,
-                             void* ws, size_t ws_bytes, hipStream_t st) {
+                             void* ws, size_t ws_bytes, int epoch, hipStream_t st) {
     if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
     if ((int64_t)R * cap >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) || nfeat >= ((int64_t)1 << 32)) return ARMNET_ERR_UNSUPPORTED;
     const OwnerMap om = make_owner_map(R);
@@ -329,26 +412,31 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
     if (n == 0) ARMNET_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * R, st));   // (otherwise the emit pass writes every count)
     unsigned char* mark = reinterpret_cast<unsigned char*>(ws);
-    int32_t* grp_base = reinterpret_cast<int32_t*>(mark + P);
+    unsigned char* rank = mark + P;
+    int32_t* grp_base = reinterpret_cast<int32_t*>(rank + P);
     int* sums = reinterpret_cast<int*>(grp_base + P / 256);
     int* base = sums + nchunk;
     int64_t* cap_out = reinterpret_cast<int64_t*>(base + nchunk);
-    ARMNET_HIP_TRY(hipMemsetAsync(mark, 0, (size_t)P, st));
+    // epoch 0: a map in an unknown state — zero it and mark with 1; 1..255: the caller vouches that the map last saw a fill or
+    // a smaller epoch (armnet_hip/sharded.py cycles 0, 2, 3, .., 255, 0, ..)
+    if (epoch == 0) ARMNET_HIP_TRY(hipMemsetAsync(mark, 0, (size_t)P, st));
+    const unsigned char ep = (unsigned char)(epoch == 0 ? 1 : epoch);
+    const uint32_t e4 = 0x01010101u * ep;
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
     if (n > 0) {
-        if (id_type == ARMNET_ID_I64) uniq_mark_bytes_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, mark, id_status);
-        else uniq_mark_bytes_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, mark, id_status);
+        if (id_type == ARMNET_ID_I64) uniq_mark_bytes_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, mark, ep, id_status);
+        else uniq_mark_bytes_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, mark, ep, id_status);
         ARMNET_LAUNCH_CHECK();
     }
-    uniq_chunk_sums_kernel<<<(int)nchunk, RF_TPB, 0, st>>>(mark, sums);
+    uniq_chunk_sums_kernel<<<(int)nchunk, RF_TPB, 0, st>>>(mark, e4, sums);
     ARMNET_LAUNCH_CHECK();
     const int cpo = (int)(Lp / RF_CHUNK);
     if (cpo <= 8192) {
-        uniq_emit_kernel<true><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, sums, counts, send_pad, grp_base, cap_out, overflow);
+        uniq_emit_kernel<true><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, e4, rank, sums, counts, send_pad, grp_base, cap_out, overflow);
     } else {
         uniq_scan_kernel<<<1, 1024, 0, st>>>((int)nchunk, cpo, R, cap, sums, base, counts, overflow);
         ARMNET_LAUNCH_CHECK();
-        uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, base, counts, send_pad, grp_base, cap_out, overflow);
+        uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, e4, rank, base, counts, send_pad, grp_base, cap_out, overflow);
     }
     ARMNET_LAUNCH_CHECK();
     if (perm_pad) return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, ws, ws_bytes, st);
@@ -372,7 +460,22 @@ extern "C" int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type,
         return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
-                                    workspace, (size_t)ws_bytes, (hipStream_t)stream);
+                                    workspace, (size_t)ws_bytes, 0, (hipStream_t)stream);
+}
+
+// The same with a caller-managed MARK EPOCH for the de-duplicating route (dedup != 0): epoch 0 = armnet_shard_route_fixed
+// (the map is zeroed, marks are 1); epoch e in 2..255 = no fill, marks are e — valid when the previous call on this workspace
+// used epoch 0 or a smaller e (a caller cycles 0, 2, 3, .., 255, 0, ..): the 1-byte-per-row map is then zeroed once per 255 steps.
+extern "C" int armnet_shard_route_fixed_epoch(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap,
+                                              int dedup, int32_t* send_pad, int32_t* perm_pad, int32_t* counts,
+                                              int32_t* overflow, int32_t* id_status, void* workspace, int64_t ws_bytes,
+                                              int epoch, void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || cap < 1 || !send_pad || !counts || !overflow || (n > 0 && (!ids || (!perm_pad && !dedup))))
+        return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (epoch < 0 || epoch == 1 || epoch > 255) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
+                                    workspace, (size_t)ws_bytes, epoch, (hipStream_t)stream);
 }
 
 extern "C" int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
@@ -380,4 +483,17 @@ extern "C" int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_
     if (n < 0 || R < 1 || nfeat <= 0 || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, workspace, (size_t)ws_bytes, (hipStream_t)stream);
+}
+
+// the owner-side gather out[j, :] = table[idx[j], :] (idx: int32 local row indices of a request list; out-of-range -> row 0)
+// and the position gather of armnet_shard_route_fixed_perm in one launch (see gather_rows_perm_kernel)
+extern "C" int armnet_shard_gather_perm_f32(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows,
+                                            float* out, int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                                            int32_t* perm_pad, const void* workspace, int64_t ws_bytes, void* stream) {
+    if (n_rows < 0 || n < 0 || E <= 0 || R < 1 || nfeat <= 0 || table_rows <= 0) return ARMNET_ERR_BAD_ARG;
+    if ((n_rows > 0 && (!idx || !table || !out)) || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (n_rows * (int64_t)E >= ((int64_t)1 << 40)) return ARMNET_ERR_UNSUPPORTED;
+    return launch_shard_gather_perm(n_rows, E, idx, table, table_rows, out, n, ids, id_type, R, nfeat, perm_pad, workspace,
+                                    (size_t)ws_bytes, (hipStream_t)stream);
 }

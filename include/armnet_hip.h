@@ -283,9 +283,27 @@ int armnet_shard_pad_route(int64_t n, int R, int64_t cap, const int32_t* counts,
  * armnet_shard_route_fixed_perm on the same workspace — the request list does not depend on it, so a caller can run it on a
  * side stream beside the index exchange and the owner-side gather (the workspace must stay untouched until it is done).
  */
+/*
+ * armnet_shard_gather_perm_f32 — the owner-side gather of a request list, out[j, :] = table[idx[j], :] (int32 local row
+ * indices; an index outside [0, table_rows) reads row 0), AND the position gather of armnet_shard_route_fixed_perm as one
+ * launch: both depend only on armnet_shard_route_fixed(dedup != 0, perm_pad = NULL) — on one rank idx is its send_pad, on
+ * several the received request list —, both are needed only by the consumer of the rows, and they are bound by different
+ * parts of the memory system, so their blocks overlap instead of queueing.
+ */
+int armnet_shard_gather_perm_f32(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows,
+                                 float* out, int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                                 int32_t* perm_pad, const void* workspace, int64_t ws_bytes, void* stream);
 int64_t armnet_shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup);
 int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
                                   const void* workspace, int64_t ws_bytes, void* stream);
+/* armnet_shard_route_fixed with a caller-managed MARK EPOCH for dedup != 0: the byte map holds the epoch of the last step that
+ * marked a position, a step's marks are the bytes equal to its epoch.  epoch 0 = armnet_shard_route_fixed (the call zeroes the
+ * map, marks are 1); epoch e in 2..255 = no fill — valid when the previous call on this workspace (same R, nfeat) used epoch 0
+ * or a smaller e.  A caller cycling 0, 2, 3, .., 255, 0, .. zeroes the map once per 255 steps.  Not for a step captured in a
+ * hipGraph (the replay would repeat the epoch). */
+int armnet_shard_route_fixed_epoch(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
+                                   int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
+                                   int32_t* id_status, void* workspace, int64_t ws_bytes, int epoch, void* stream);
 int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
                              int32_t* id_status, void* workspace, int64_t ws_bytes, void* stream);

@@ -649,6 +649,55 @@ def test_position_gather_on_a_side_stream_gives_the_in_order_result(R, dtype):
     assert int(overflow.item()) == 0
 
 
+@pytest.mark.parametrize("R,dtype,E", [(1, torch.int64, 16), (8, torch.int32, 10), (3, torch.int64, 7), (2, torch.int64, 64)])
+def test_owner_gather_and_position_gather_in_one_launch(R, dtype, E):
+    """armnet_shard_gather_perm_f32 (the owner-side gather and the position gather of the de-duplicating route as one launch)
+    against armnet_gather_scale_f32 + the one-call route: same rows bit for bit, same perm_pad; 16- / 8- / 4-byte chunks;
+    an index outside the shard reads row 0; step after step on the same workspace"""
+    from armnet_hip import native
+    from armnet_hip.sharded import HipShardOps
+    nfeat, n = 200_003, 39 * 4099
+    ops = HipShardOps()
+    cap = (nfeat + R - 1) // R
+    overflow = torch.zeros(1, device=DEV, dtype=torch.int32)
+    shard = torch.randn(cap + 3, E, generator=torch.Generator().manual_seed(E)).to(DEV)
+    for step in range(3):
+        ids = torch.randint(0, nfeat, (n,), generator=torch.Generator().manual_seed(10 * R + step)).to(dtype).to(DEV)
+        sp0, pp0 = ops.route_fixed(ids, R, nfeat, cap, True, overflow)
+        sp1, pp1 = ops.route_fixed(ids, R, nfeat, cap, True, overflow, perm_with_gather=True)
+        pending = pp1._armnet_pending
+        idx = sp1.clone()
+        if step == 2:
+            idx[5] = shard.shape[0] + 7                          # (never produced by the routing: contract of the entry point)
+        rows1 = ops.gather_perm(idx, shard, pending)
+        want = ops.gather(torch.where(idx < shard.shape[0], idx, torch.zeros_like(idx)), shard)
+        assert torch.equal(sp0, sp1) and torch.equal(pp0, pp1) and torch.equal(rows1, want), step
+    assert int(overflow.item()) == 0
+
+
+def test_mark_epochs_give_the_filled_map_result_over_a_full_cycle():
+    """armnet_shard_route_fixed_epoch: 300 steps on one workspace with the byte map zeroed once per 255 steps (epochs 0, 2, ..,
+    255, 0, ..) against the same steps with a fill per step — same slots, same positions, every step (a stale mark of an
+    earlier step would add a request)"""
+    from armnet_hip.sharded import HipShardOps
+    nfeat, n, R = 50_021, 8191, 4
+    a, b = HipShardOps(), HipShardOps()
+    b.mark_epochs = False
+    cap = (nfeat + R - 1) // R
+    overflow = torch.zeros(1, device=DEV, dtype=torch.int32)
+    g = torch.Generator().manual_seed(77)
+    for step in range(300):
+        ids = torch.randint(0, nfeat, (n,), generator=g).to(DEV)
+        sa, pa = a.route_fixed(ids, R, nfeat, cap, True, overflow)
+        sb, pb = b.route_fixed(ids, R, nfeat, cap, True, overflow)
+        assert torch.equal(sa, sb) and torch.equal(pa, pb), step
+    # a workspace whose layout changes starts a new cycle
+    sa, pa = a.route_fixed(ids, 2, nfeat, (nfeat + 1) // 2, True, overflow)
+    sb, pb = b.route_fixed(ids, 2, nfeat, (nfeat + 1) // 2, True, overflow)
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
+    assert int(overflow.item()) == 0
+
+
 def test_row_sharded_step_is_bit_equal_with_the_fused_and_the_round3_routing():
     """both routings of the fixed protocol (armnet_shard_route_fixed | route + pad_route) feed the same rows to the fused
     kernel: bit-equal outputs, with and without de-duplication"""
@@ -664,10 +713,11 @@ def test_row_sharded_step_is_bit_equal_with_the_fused_and_the_round3_routing():
         m._shard.whole_shard = False
         for dedup in (False, True):
             for fused in (True, False):
-                m._shard.dedup, m._shard.fused_route = dedup, fused
-                got = m.arm_block(idt, vt.clone())
-                assert m._shard.last_path == "fixed" and not m._shard.overflowed()
-                assert torch.equal(got, want), (dedup, fused)
+                for gwp in ((True, False) if (dedup and fused) else (True,)):       # position gather inside the owner gather's launch | own launch
+                    m._shard.dedup, m._shard.fused_route, m._shard.gather_with_perm = dedup, fused, gwp
+                    got = m.arm_block(idt, vt.clone())
+                    assert m._shard.last_path == "fixed" and not m._shard.overflowed()
+                    assert torch.equal(got, want), (dedup, fused, gwp)
 
 
 @pytest.mark.parametrize("name", ["g5_avazu_mh4_ens_a1.7_stress", "g5_avazu_1h_ens_a2.0_fresh", "g12_criteo_mh4_h8_e10_a2.0_ens_mlp500_dnn500",

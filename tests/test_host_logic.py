@@ -50,8 +50,13 @@ def test_abi_argument_validation_without_device():
     f32 = ctypes.c_float
     assert lib.armnet_shard_route_fixed(i64(8), None, 0, 2, i64(100), i64(16), 0, *([None] * 6), i64(0), None) == native.ERR_BAD_ARG
     assert lib.armnet_shard_route_fixed_perm(i64(8), None, 0, 2, i64(100), None, None, i64(0), None) == native.ERR_BAD_ARG
+    assert lib.armnet_shard_gather_perm_f32(i64(8), 16, None, None, i64(10), None, i64(0), None, 0, 1, i64(100), None, None, i64(0), None) == native.ERR_BAD_ARG
+    assert lib.armnet_shard_gather_perm_f32(i64(0), 16, None, None, i64(10), None, i64(0), None, 0, 1, i64(100), None, None, i64(0), None) == native.OK
+    for bad_epoch in (-1, 1, 256):
+        assert lib.armnet_shard_route_fixed_epoch(i64(0), None, 0, 2, i64(100), i64(16), 1, ctypes.c_void_p(8), None, ctypes.c_void_p(8),
+                                                  ctypes.c_void_p(8), None, None, i64(0), bad_epoch, None) == native.ERR_BAD_ARG
     lib.armnet_shard_route_fixed_ws_bytes.restype = ctypes.c_int64
-    assert lib.armnet_shard_route_fixed_ws_bytes(0, i64(100), 1) == -1 and 1_000_000 < lib.armnet_shard_route_fixed_ws_bytes(8, i64(1_000_000), 1) < 1_100_000
+    assert lib.armnet_shard_route_fixed_ws_bytes(0, i64(100), 1) == -1 and 2_000_000 < lib.armnet_shard_route_fixed_ws_bytes(8, i64(1_000_000), 1) < 2_100_000
     assert lib.armnet_linear_small_f32(i64(4), 8, 17, None, i64(8), None, None, f32(1.0), None, i64(17), 0, None) == native.ERR_UNSUPPORTED
     assert lib.armnet_linear_small_f32(i64(4), 8, 2, None, i64(4), None, None, f32(1.0), None, i64(2), 0, None) == native.ERR_BAD_ARG   # ldx < K
     assert lib.armnet_linear_small_f32(i64(0), 8, 2, None, i64(8), None, None, f32(1.0), None, i64(2), 0, None) == native.OK
