@@ -4,8 +4,8 @@
 
 namespace armnet {
 
-// nemb 4..32, nfield <= 48, any afn_hid (slices); wider shapes keep the composed device ops (siblings.py)
-static bool afn_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 32 || O < 1 || F < 1 || F > 48); }
+// nemb 4..64, nfield <= 48, any afn_hid (slices); wider shapes keep the composed device ops (siblings.py)
+static bool afn_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 64 || O < 1 || F < 1 || F > 48); }
 
 template <int E>
 static int launch_afn_nq(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st) {
@@ -25,7 +25,7 @@ static int launch_afn_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st)
     if (!afn_bwd_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
-    const int slice = 16 * bwd_passes(a.E <= 16 ? 16 : 32);
+    const int slice = 16 * bwd_passes_model(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64, MODEL_AFN);
     for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
         BwdExtra gx = gx0;
@@ -38,7 +38,8 @@ static int launch_afn_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st)
         s.dz = a.dz + (size_t)o0 * a.E;
         if (a.bn_a) { s.bn_a = a.bn_a + o0; s.bn_b = a.bn_b + o0; s.bn_c = a.bn_c + o0; }
         s.d_values = a.d_values + (size_t)o0 * a.F;
-        const int rc = a.E <= 16 ? launch_afn_nq<16>(s, gx, nq, st) : launch_afn_nq<32>(s, gx, nq, st);
+        const int rc = a.E <= 16 ? launch_afn_nq<16>(s, gx, nq, st) : a.E <= 32 ? launch_afn_nq<32>(s, gx, nq, st)
+                                                                                : launch_afn_nq<64>(s, gx, nq, st);
         if (rc != ARMNET_OK) return rc;
     }
     return ARMNET_OK;

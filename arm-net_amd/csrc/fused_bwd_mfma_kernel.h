@@ -43,6 +43,8 @@ namespace armnet {
 // (the 512-register budget holds the dx tiles of up to 32 fields beside the staged rows and dz / z)
 constexpr int bwd_passes(int E) { return E >= 128 ? 1 : E >= 64 ? ARMNET_BWD_E64_PASSES : E > 16 ? 2 : ARMNET_BWD_E16_PASSES; }
 constexpr int bwd_blocks_per_cu(int E) { return E >= 128 ? 1 : ARMNET_BWD_BLOCKS_PER_CU; }
+// the siblings at nemb 33..64: one pass per launch — their second dx accumulator set takes the registers of the second pass
+constexpr int bwd_passes_model(int E, int model) { return (model != MODEL_ARM && E >= 64) ? 1 : bwd_passes(E); }
 
 // MODEL_GC_ARM (models/gc_arm.py:82-95, round 4): the same kernel for GC-ARM's block
 //     arm[b,o,:] = sum_f w[b,o,f] y[b,f,:],   y = emb_bn(exp(x)) = emb_scale[f] * exp(x[b,f,:]) + emb_shift[f]   (no outer exp)
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     const float two_m_alpha = 2.0f - a.alpha;
 
     // per-wave accumulators over all its samples: d_values in the C layout, d_qfold^T as MFMA #4's accumulator
-    constexpr int NTS = bwd_passes(E);
+    constexpr int NTS = bwd_passes_model(E, MODEL);
     f32x2 dvacc[NTS][NP];                     // pairs (2jp, 2jp+1) like the gate registers
     f32x4 dqacc[NTS][EB];
     [[maybe_unused]] float dbacc[NTS];        // AFN: this lane's part of d_bias[16 nt + c]
@@ -850,11 +852,12 @@ int launch_bwd_mfma_e16(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e32(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e64(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e128(const BwdArgs& a, int nq, hipStream_t st);    // nq 2..8 (wider samples do not fit the LDS)
-// GC-ARM (fused_bwd_gc_*.hip): nemb <= 32
+// GC-ARM (fused_bwd_gc_*.hip): nemb <= 64
 int launch_bwd_gc_e16(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 int launch_bwd_gc_e32(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
+int launch_bwd_gc_e64(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 
-// AFN (fused_bwd_afn.hip): nemb <= 32; no sparse map, so one solver-mode instantiation per shape
+// AFN (fused_bwd_afn.hip): nemb <= 64; no sparse map, so one solver-mode instantiation per shape
 template <int E, int NQ>
 static int launch_bwd_afn_t(const BwdArgs& a, const BwdExtra& gx, hipStream_t st) {
     if (a.id_type == ARMNET_ID_I64) return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, 0, MODEL_AFN>(a, gx, st);

@@ -350,7 +350,7 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
 
 /*
  * GC-ARM's block backward on the matrix cores (round 4) — the training step of `train.py:108-114 --model gc_arm`
- * (models/gc_arm.py:82-95 under autograd), one kernel per slice of 64 (nemb <= 16) / 32 neurons:
+ * (models/gc_arm.py:82-95 under autograd), one kernel per slice of 64 (nemb <= 16) / 32 (nemb <= 32) / 16 (nemb <= 64) neurons:
  *   inputs as armnet_gc_fused_fwd_f32; emb_scale / emb_shift = the affine emb_bn applies to exp(x) in THIS step
  *   (training mode: from the batch statistics, armnet_bn_finalize_f32);  z = the pre-arm_bn block output of the forward
  *   run with an identity bn_scale / bn_shift;  dy = the gradient of z, or — with coefA/B/C (armnet_bn_bwd_coef_f32, all
@@ -364,7 +364,7 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
  * The global context (gc_arm.py:37-41) adds the same number to every gate of a row; the sparse map is invariant to
  * that, its Jacobian's rows sum to zero, and the context's gradient is analytically zero (the reference's autograd
  * produces rounding noise there) — it is not formed.
- * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..32, nfield <= 48); otherwise
+ * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..64, nfield <= 48); otherwise
  * ARMNET_ERR_UNSUPPORTED and the caller keeps its composed device ops.
  */
 /*

@@ -148,6 +148,7 @@ def _analytically_zero(m):
 GC_FUSED_SHAPES = [  # nfield, nemb, nhead, arm_hid, alpha, batch  (one / several neuron slices, padded nemb, every solver)
     (39, 16, 2, 32, 1.7, 512), (10, 10, 1, 20, 2.0, 300), (22, 32, 2, 8, 1.5, 257), (5, 8, 3, 7, 1.0, 130),
     (43, 16, 1, 70, 2.5, 96), (48, 12, 4, 40, 2.0, 64), (3, 4, 1, 1, 1.3, 33), (30, 27, 2, 24, 1.5, 200),
+    (22, 64, 2, 20, 2.0, 100), (39, 48, 1, 33, 1.7, 70),          # nemb 33..64: one 16-neuron pass per launch
 ]
 
 
@@ -206,7 +207,7 @@ def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alph
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("F,E,O,B", [(39, 16, 64, 512), (10, 10, 20, 300), (22, 32, 40, 257), (5, 8, 7, 130), (43, 16, 70, 96),
-                                     (48, 12, 100, 64), (3, 4, 1, 33), (30, 27, 24, 200)])
+                                     (48, 12, 100, 64), (3, 4, 1, 33), (30, 27, 24, 200), (22, 64, 40, 100), (39, 48, 33, 70)])
 def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
     """AFN's training step through armnet_afn_fused_bwd_f32 against the composed device ops (see the GC-ARM test above)"""
     from armnet_hip import native
@@ -256,8 +257,8 @@ def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
 
 @pytest.mark.gpu
 def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
-    """armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32 on ~230 of the shapes of tools/sibling_bwd_scan.py (7 239 there:
-    every nfield 1..48, nemb 4..32, one / two neuron slices, every solver) against the backward written out in float64"""
+    """armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32 on ~330 of the shapes of tools/sibling_bwd_scan.py (every nfield
+    1..48, nemb 4..64, one to five neuron slices, every solver there) against the backward written out in float64"""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "sibling_bwd_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sibling_bwd_scan.py"))
@@ -266,13 +267,13 @@ def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
     g = torch.Generator().manual_seed(0)
     n = 0
     for F in (1, 2, 3, 4, 5, 9, 16, 17, 22, 31, 39, 40, 43, 48):
-        for E in (4, 7, 10, 16, 17, 31, 32):
+        for E in (4, 7, 10, 16, 17, 31, 32, 33, 47, 64):
             if (F + E) % 2:
                 continue
             for O, kind, alpha in ((1, "gc", 2.0), (20, "gc", 1.7), (70, "gc", 1.0), (70, "gc", 1.5), (20, "afn", 1.0), (70, "afn", 1.0)):
                 assert scan.case(kind, F, E, O, alpha, 37, g) == 0.0, (kind, F, E, O, alpha)
                 n += 1
-    assert n > 200
+    assert n > 300
 
 
 @pytest.mark.gpu
