@@ -274,6 +274,10 @@ def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
                 assert scan.case(kind, F, E, O, alpha, 37, g) == 0.0, (kind, F, E, O, alpha)
                 n += 1
     assert n > 300
+    for B in (1, 2, 5, 64, 65, 1025, 4099):                                      # batch sizes around the wave / block granularity
+        for F, E, O, kind, alpha in ((39, 16, 64, "gc", 1.7), (22, 32, 33, "gc", 1.5), (5, 64, 17, "gc", 1.0),
+                                     (39, 16, 64, "afn", 1.0), (7, 64, 16, "afn", 1.0)):
+            assert scan.case(kind, F, E, O, alpha, B, g) == 0.0, (kind, F, E, O, alpha, B)
 
 
 @pytest.mark.gpu
