@@ -296,6 +296,8 @@ def gc_fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, val
         _dev_f32(t, n)
     coefs = (coefA, coefB, coefC)
     if any(c is not None for c in coefs):
+        if any(c is None for c in coefs):
+            raise ArmnetNativeError("coefA / coefB / coefC: all three (armnet_bn_bwd_coef_f32) or none")
         for n, t in zip(("coefA", "coefB", "coefC"), coefs):
             _dev_f32(t, n)
     if d_y.numel() != B * F * E:
@@ -346,6 +348,8 @@ def afn_fused_bwd(B, F, E, O, flags, ids, vals, table, weight, emb_scale, emb_sh
     for n, t in zip(("vals", "table", "weight", "emb_scale", "emb_shift", "z", "dy", "d_weight", "d_bias", "d_y"), ts):
         _dev_f32(t, n)
     if any(c is not None for c in (coefA, coefB, coefC)):
+        if any(c is None for c in (coefA, coefB, coefC)):
+            raise ArmnetNativeError("coefA / coefB / coefC: all three (armnet_bn_bwd_coef_f32) or none")
         for n, t in zip(("coefA", "coefB", "coefC"), (coefA, coefB, coefC)):
             _dev_f32(t, n)
     if d_y.numel() != B * F * E:

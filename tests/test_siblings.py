@@ -282,6 +282,46 @@ def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["gc", "afn"])
+def test_sibling_backward_without_batchnorm_coefficients_is_the_identity_coefficients(kind):
+    """coefA/B/C = NULL (dy is the gradient of the block's own output) against explicit {1, 0, 0} coefficients: same
+    launch, same arithmetic — bit-equal outputs except the float-atomic accumulators (tolerance), int32 ids as well"""
+    from armnet_hip import native
+    B, F, E, O, nfeat, alpha = 301, 22, 16, 40, 503, 1.7
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(torch.int32).to(DEV)
+    vals = (torch.rand(B, F, generator=g) * 0.999 + 1e-3).to(DEV)
+    table = (torch.rand(nfeat, E, generator=g) * 0.9 + 0.05).to(DEV)
+    qf = (torch.randn(O, E, generator=g) * 0.8).to(DEV)
+    values = (torch.randn(O, F, generator=g) * 0.4).to(DEV)
+    es, et = (torch.rand(F, generator=g) + 0.5).to(DEV), (torch.randn(F, generator=g) * 0.3).to(DEV)
+    z, dz = torch.rand(B, O, E, generator=g).to(DEV), torch.randn(B, O, E, generator=g).to(DEV)
+    one, zero = torch.ones(O, device=DEV), torch.zeros(O, device=DEV)
+    outs = []
+    for coefs in ((None, None, None), (one, zero, zero)):
+        d_table, d_y = torch.zeros(nfeat, E, device=DEV), torch.empty(B, F, E, device=DEV)
+        if kind == "gc":
+            d_v, d_q = torch.zeros(O, F, device=DEV), torch.zeros(O, E, device=DEV)
+            native.gc_fused_bwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, es, et, z, dz, *coefs, d_table, d_v, d_q, d_y)
+            outs.append((d_y, d_table, d_v, d_q))
+        else:
+            d_w, d_b = torch.zeros(O, F, device=DEV), torch.zeros(O, device=DEV)
+            native.afn_fused_bwd(B, F, E, O, 0, ids, vals, table, values, es, et, z, dz, *coefs, d_w, d_b, d_y)
+            outs.append((d_y, d_w, d_b))
+    assert torch.equal(outs[0][0], outs[1][0])                               # d_y: plain stores
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)
+    with pytest.raises(native.ArmnetNativeError):                            # all three or none
+        if kind == "gc":
+            native.gc_fused_bwd(B, F, E, O, alpha, 50, 0, ids, vals, table, qf, values, es, et, z, dz, one, None, None,
+                                torch.zeros(nfeat, E, device=DEV), torch.zeros(O, F, device=DEV), torch.zeros(O, E, device=DEV),
+                                torch.empty(B, F, E, device=DEV))
+        else:
+            native.afn_fused_bwd(B, F, E, O, 0, ids, vals, table, values, es, et, z, dz, one, None, None,
+                                 torch.zeros(O, F, device=DEV), torch.zeros(O, device=DEV), torch.empty(B, F, E, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gc", "afn"])
 def test_sibling_graphed_train_step_equals_eager_steps(kind):
     """the fused sibling training step inside armnet_hip.modules.GraphedTrainStep (one hipGraph: no host sync, no
     allocation inside the autograd.Functions that a capture cannot replay) against the same SGD steps run eagerly"""
