@@ -188,6 +188,7 @@ int launch_clamp_vals(float* vals, int64_t n, hipStream_t s) {
 // A block owns TPB consecutive rows = one contiguous span of TPB*d floats: it is read coalesced,
 // transposed through LDS so that thread r owns row r as the LDS column  lds[i*(TPB+1) + r]
 // (odd stride: conflict-free both for the transposing writes and the per-thread column reads).
+constexpr int EL_U = 8;
 template <int TPB>
 __global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ X,
                                   float* __restrict__ P) {
@@ -198,17 +199,34 @@ __global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const f
         const int n = nr * d;
         const float* src = X + r0 * d;
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += TPB) {
-            const int r = k / d, i = k - r * d;
-            lds[i * S + r] = src[k];
+        // EL_U loads per thread in flight (a loop of one load, one LDS write leaves a CU with 8 KB in flight: 2.2 TB/s);
+        // (row, column) of element k advance by TPB per step without a division
+        const int qd = TPB / d, rd = TPB - qd * d;
+        {
+            int r = threadIdx.x / d, i = threadIdx.x - r * d;
+            for (int k0 = threadIdx.x; k0 < n; k0 += TPB * EL_U) {
+                float v[EL_U];
+#pragma unroll
+                for (int u = 0; u < EL_U; ++u) v[u] = (k0 + u * TPB < n) ? src[k0 + u * TPB] : 0.f;
+#pragma unroll
+                for (int u = 0; u < EL_U; ++u) {
+                    if (k0 + u * TPB < n) lds[i * S + r] = v[u];
+                    r += qd; i += rd;
+                    if (i >= d) { i -= d; ++r; }
+                }
+            }
         }
         __syncthreads();
         if ((int)threadIdx.x < nr) sparse_map_row(lds + threadIdx.x, S, d, cfg);
         __syncthreads();
         float* dst = P + r0 * d;
-        for (int k = threadIdx.x; k < n; k += TPB) {
-            const int r = k / d, i = k - r * d;
-            dst[k] = lds[i * S + r];
+        {
+            int r = threadIdx.x / d, i = threadIdx.x - r * d;
+            for (int k = threadIdx.x; k < n; k += TPB) {
+                dst[k] = lds[i * S + r];
+                r += qd; i += rd;
+                if (i >= d) { i -= d; ++r; }
+            }
         }
     }
 }
@@ -263,10 +281,30 @@ __global__ void entmax_bwd_lds_kernel(int64_t rows, int d, float alpha, const fl
         const int nr = (int)((rows - r0) < TPB ? (rows - r0) : TPB);
         const int n = nr * d;
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += TPB) {
-            const int r = k / d, i = k - r * d;
-            ly[i * S + r] = Y[r0 * d + k];
-            lg[i * S + r] = dY[r0 * d + k];
+        const int qd = TPB / d, rd = TPB - qd * d;
+        {
+            const float* sy = Y + r0 * d;
+            const float* sg = dY + r0 * d;
+            int r = threadIdx.x / d, i = threadIdx.x - r * d;
+            constexpr int U = EL_U / 2;                            // two arrays: the same number of loads in flight
+            for (int k0 = threadIdx.x; k0 < n; k0 += TPB * U) {
+                float vy[U], vg[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = k0 + u * TPB < n;
+                    vy[u] = in ? sy[k0 + u * TPB] : 0.f;
+                    vg[u] = in ? sg[k0 + u * TPB] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k0 + u * TPB < n) {
+                        ly[i * S + r] = vy[u];
+                        lg[i * S + r] = vg[u];
+                    }
+                    r += qd; i += rd;
+                    if (i >= d) { i -= d; ++r; }
+                }
+            }
         }
         __syncthreads();
         if ((int)threadIdx.x < nr) {
@@ -292,9 +330,14 @@ __global__ void entmax_bwd_lds_kernel(int64_t rows, int d, float alpha, const fl
             }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += TPB) {
-            const int r = k / d, i = k - r * d;
-            dX[r0 * d + k] = lg[i * S + r];
+        {
+            float* dst = dX + r0 * d;
+            int r = threadIdx.x / d, i = threadIdx.x - r * d;
+            for (int k = threadIdx.x; k < n; k += TPB) {
+                dst[k] = lg[i * S + r];
+                r += qd; i += rd;
+                if (i >= d) { i -= d; ++r; }
+            }
         }
     }
 }
