@@ -278,18 +278,34 @@ __global__ void bn_bwd_scatter_kernel(int64_t n_rows, int C, int E, const IdT* _
                                       const float* __restrict__ dy, const float* __restrict__ coefA,
                                       const float* __restrict__ coefB, const float* __restrict__ coefC, int64_t nfeat,
                                       float* __restrict__ d_table) {
-    const int64_t total = n_rows * E;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / E;
-        const int e = (int)(i - r * E);
-        const int f = (int)(r % C);
-        bool bad;
-        const uint32_t id = load_id_checked(ids + r, nfeat, bad);
-        if (bad) continue;                               // the forward already raised on it
-        const float tv = t[i];
-        const float dt = fmaf(coefA[f], dy[i], fmaf(coefC[f], tv, coefB[f]));
-        const float dx = MAP == 0 ? dt * tv : dt * __expf(-tv);
-        unsafeAtomicAdd(d_table + (size_t)id * E + e, dx * vals[r]);
+    const int64_t total = n_rows * E, stride = (int64_t)gridDim.x * blockDim.x;
+    constexpr int U = 4;                                 // elements per thread in flight (loads of U trips before the atomics)
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * U) {
+        uint32_t id[U];
+        float tv[U], gv[U], vv[U];
+        int f[U], e[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < total;
+            const int64_t ic = ok[u] ? i : total - 1;
+            const int64_t r = ic / E;
+            e[u] = (int)(ic - r * E);
+            f[u] = (int)(r % C);
+            bool bad;
+            id[u] = load_id_checked(ids + r, nfeat, bad);
+            ok[u] = ok[u] && !bad;                       // the forward already raised on a bad id
+            tv[u] = t[ic];
+            gv[u] = dy[ic];
+            vv[u] = vals[r];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float dt = fmaf(coefA[f[u]], gv[u], fmaf(coefC[f[u]], tv[u], coefB[f[u]]));
+            const float dx = MAP == 0 ? dt * tv[u] : dt * __expf(-tv[u]);
+            if (ok[u]) unsafeAtomicAdd(d_table + (size_t)id[u] * E + e[u], dx * vv[u]);
+        }
     }
 }
 }  // namespace armnet
