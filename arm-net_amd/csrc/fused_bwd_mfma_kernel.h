@@ -281,8 +281,16 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     // prefetch depth by register budget: 2 = rows of the next sample + ids of the one after + dz/z one pass ahead
     // (nemb <= 16), 1 = ids of the next sample + dz/z one pass ahead (nemb <= 32), 0 = nothing carried (nemb = 64)
     constexpr int PF = (E <= 16 && NQ <= 6) ? 2 : (E <= 16 || (E <= 32 && NQ <= 8)) ? 1 : 0;
+    // PF == 1, LATE (round 4): the next sample's rows are requested BEHIND the passes, in front of the scatter — their registers are
+    // live only while the dx atomics go out, not across the passes (where depth 2 does not fit), and the gather no longer waits
+    // at the top of every sample
+#ifdef ARMNET_BWD_NO_LATE_ROWS
+    constexpr bool LATE = false;
+#else
+    constexpr bool LATE = (PF == 1);
+#endif
     if (b_first < Bi) {
-        if constexpr (PF == 2) {
+        if constexpr (PF == 2 || LATE) {
             fetch_ids(b_first, idC, vC);
             fetch_zd(b_first, 0);
             fetch_rows();
@@ -296,7 +304,7 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
     for (int b = b_first; b < Bi; b += nwaves) {
         // ---- stage the sample's rows (scaled) into the wave's tile; remember id / value per tile row ----
         wave_lds_fence();
-        if constexpr (PF == 1) {
+        if constexpr (PF == 1 && !LATE) {
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
                 idC[n] = idN[n];
@@ -742,6 +750,16 @@ __global__ void __launch_bounds__(256, bwd_blocks_per_cu(E)) fused_bwd_mfma_kern
 #undef XP_SET
 #undef VV
 #undef DG
+        }
+        if constexpr (LATE) {
+            // next sample's rows (its ids arrived during this sample), ids / values of the one after
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                idC[n] = idN[n];
+                vC[n] = vN[n];
+            }
+            fetch_rows();
+            fetch_ids(b + 2 * nwaves, idN, vN);
         }
         // ---- scatter: d_table[id[f], e] += dx[f, e] * val[f]   (x = table[id] * val, layers.py:20-21) ----------
 #pragma unroll
