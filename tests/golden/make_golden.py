@@ -318,6 +318,7 @@ def main():
     sibling_cases()
     wide_head_cases()
     sibling_grad_cases()
+    round4_sibling_grad_cases()
 
 
 def run_sh_cases():
@@ -541,6 +542,15 @@ def sibling_grad_cases():
     _sibling_grad_case("s3_grad_afn_h16_evalbn_b64", "afn", base(22, 128, 16, 2.0, 16, mlp_nhid=16), 64, 166, False)
 
 
+def round4_sibling_grad_cases():
+    """round 4: the siblings' fused training step (armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32) at the kernel families the
+    round-3 fixtures do not reach: nemb padded to 32 and to 64 (one 16-neuron pass per launch, several slices), alpha = 1.5"""
+    _sibling_grad_case("s3_grad_gcarm_k2_e48_a1.5_train_b128", "gc", base(13, 128, 48, 1.5, 12, nhead=2, mlp_nhid=16), 128, 171, True)
+    _sibling_grad_case("s3_grad_gcarm_k1_e24_a2.0_ens_train_b128", "gc",
+                       base(10, 128, 24, 2.0, 20, nhead=1, ensemble=True, mlp_nhid=16, deep_nhid=16), 128, 172, True)
+    _sibling_grad_case("s3_grad_afn_h20_e40_train_b128", "afn", base(10, 128, 40, 2.0, 20, mlp_nhid=16), 128, 173, True)
+
+
 def sibling_cases():
     for alpha in (1.0, 1.7, 2.0):
         _sibling_case(f"s1_gcarm_criteo_k2_a{alpha}_stress", "gc", base(39, 512, 16, alpha, 16, nhead=2), 16, 151, "stress")
@@ -616,6 +626,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "--round3-only":      # add the round-3 cases without rewriting the others
         wide_head_cases()
         sibling_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round4-sibling-grad-only":
+        round4_sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--sibling-grad-only":
         sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--entmax-grad-only":
