@@ -612,6 +612,15 @@ def round4_cases():
     grad_case("h4_grad_frappe_1h_e100_h10_a1.7_train", "1h", base(10, 300, 100, 1.7, 10, mlp_nhid=64), 48, 141, True)
     grad_case("h4_grad_avazu_1h_e72_h16_a2.0_evalbn", "1h", base(22, 300, 72, 2.0, 16), 24, 142, False)
     grad_case("h4_grad_criteo_1h_a1.1_train", "1h", base(39, 300, 16, 1.1, 32), 24, 143, True)
+    round4_mid_width_grad_cases()
+
+
+def round4_mid_width_grad_cases():
+    """the E = 32 and E = 64 families of the matrix-core backward (nemb 17..64; BASELINE.json configs[3] is nemb 64) against the
+    reference's own gradients — until round 4 they were held to the oracle and the shape-agnostic kernel only"""
+    grad_case("h4_grad_criteo_1h_e64_h32_a2.0_train", "1h", base(39, 300, 64, 2.0, 32), 32, 144, True)
+    grad_case("h4_grad_avazu_mh2_e32_h16_a1.7_train", "mh", base(22, 300, 32, 1.7, 16, nhead=2), 32, 145, True)
+    grad_case("h4_grad_frappe_1h_e24_h20_a1.5_evalbn", "1h", base(10, 300, 24, 1.5, 20), 32, 146, False)
 
 
 if __name__ == "__main__":
@@ -626,6 +635,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "--round3-only":      # add the round-3 cases without rewriting the others
         wide_head_cases()
         sibling_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round4-mid-width-grad-only":
+        round4_mid_width_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--round4-sibling-grad-only":
         round4_sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--sibling-grad-only":
