@@ -319,6 +319,7 @@ def main():
     wide_head_cases()
     sibling_grad_cases()
     round4_sibling_grad_cases()
+    round4_sibling_wide_cases()
 
 
 def run_sh_cases():
@@ -542,6 +543,12 @@ def sibling_grad_cases():
     _sibling_grad_case("s3_grad_afn_h16_evalbn_b64", "afn", base(22, 128, 16, 2.0, 16, mlp_nhid=16), 64, 166, False)
 
 
+def round4_sibling_wide_cases():
+    """eval-mode fixtures for the siblings in the E = 64 kernel family (nemb 33..64), which the round-2 set does not reach"""
+    _sibling_case("s1_gcarm_criteo_k2_e48_a1.7_stress", "gc", base(39, 300, 48, 1.7, 12, nhead=2), 12, 155, "stress")
+    _sibling_case("s2_afn_avazu_h24_e64_stress", "afn", base(22, 300, 64, 1.0, 24), 12, 165, "stress")
+
+
 def round4_sibling_grad_cases():
     """round 4: the siblings' fused training step (armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32) at the kernel families the
     round-3 fixtures do not reach: nemb padded to 32 and to 64 (one 16-neuron pass per launch, several slices), alpha = 1.5"""
@@ -637,6 +644,8 @@ if __name__ == "__main__":
         sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--round4-mid-width-grad-only":
         round4_mid_width_grad_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round4-sibling-wide-only":
+        round4_sibling_wide_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--round4-sibling-grad-only":
         round4_sibling_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--sibling-grad-only":
