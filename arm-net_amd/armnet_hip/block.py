@@ -1,18 +1,21 @@
 """Tensor-level wrappers over the C ABI: parameter folding cache + fused-block launch.
 
-PyTorch here is plumbing (device memory, streams); all arithmetic of the hot
-path runs in the HIP kernels.  CPU tensors are rejected — there is no fallback.
+PyTorch here is plumbing (device memory, streams); all arithmetic of the hot path runs in the HIP kernels.  Device
+tensors never leave them: there is no fallback.  A model that was never moved to the GPU, called with host tensors, runs
+the reference's ATen op chain instead (host_ops.py — a dispatch on where the tensors live, like the reference's own
+`models/model_utils.py:86`); a model and a batch on DIFFERENT devices raise.
 """
 import torch
 
-from . import native
+from . import host_ops, native
 
 
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise native.ArmnetNativeError(
-            f"{what} is on {t.device}: the ARM-Net HIP path runs on the MI355X only (no CPU fallback). "
-            "Move the model and the batch to the GPU (model.cuda(), batch['id'].cuda(), ...).")
+            f"{what} is on {t.device} while the rest of the call is on the GPU: the ARM-Net HIP kernels take device "
+            "tensors only and nothing is copied or computed elsewhere behind the caller's back (no CPU fallback). "
+            "Move the model and the batch to the same device (model.cuda(), batch['id'].cuda(), ...).")
 
 
 class ArmBlockParams:
@@ -72,7 +75,10 @@ def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alph
 
 def embedding_forward(ids, vals, table, check_ids=True):
     """layers.py:15-21 — table[ids] * vals.unsqueeze(2) -> [B, F, E]."""
+    if host_ops.on_host(ids, table) and (vals is None or not vals.is_cuda):
+        return host_ops.embedding(ids, vals, table)                  # host tensors: the reference's own ops
     _require_cuda(ids, "x['id']")
+    _require_cuda(table, "the embedding table")
     shape = tuple(ids.shape)
     E = table.shape[1]
     ids_c = ids.contiguous()
@@ -91,7 +97,9 @@ def embedding_forward(ids, vals, table, check_ids=True):
 
 
 def _entmax_raw(X, alpha, dim, n_iter, ensure_sum_one, flags):
-    _require_cuda(X, "X")
+    if not X.is_cuda:                                                # host tensor: utils/entmax.py:29-68 on ATen ops
+        with torch.no_grad():
+            return host_ops.entmax_bisect(X, float(alpha), dim, n_iter, ensure_sum_one)
     if X.dtype != torch.float32:
         raise native.ArmnetNativeError(f"entmax: float32 only, got {X.dtype}")
     nd = X.dim()

@@ -8,7 +8,7 @@ MLP head's input runs in ONE fused HIP kernel (armnet_fused_fwd_f32).
 import torch
 import torch.nn as nn
 
-from . import native
+from . import host_ops, native
 from .block import ArmBlockParams, _require_cuda, arm_block_forward, embedding_forward, entmax_forward
 
 
@@ -216,6 +216,8 @@ class HipEmbedding(nn.Module):
 
     def forward(self, x, check_ids=None):
         check = self.check_ids if check_ids is None else check_ids
+        if host_ops.on_host(x["id"], x["value"], self.embedding.weight):     # never moved to the GPU: the reference's ops
+            return host_ops.embedding(x["id"], x["value"], self.embedding.weight)
         if torch.is_grad_enabled() and self.embedding.weight.requires_grad:
             return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], check)
         return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=check)
@@ -288,11 +290,24 @@ class ArmNetBase(nn.Module):
         Inference (eval mode under no_grad, or frozen parameters): ONE fused kernel, BN folded.
         Otherwise (training, or eval with autograd on): the same kernel yields the pre-BN neurons inside
         an autograd.Function whose backward is armnet_fused_bwd_f32; arm_bn then runs as a torch module
-        (batch statistics + running-stat update in train mode, armnet_1h.py:85)."""
-        _require_cuda(vals, "x['value']")
-        _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
+        (batch statistics + running-stat update in train mode, armnet_1h.py:85).
+
+        A model that was never moved to the GPU, called with host tensors, runs the reference's ATen op chain
+        (host_ops.arm_block + the arm_bn module; differentiable) — the dispatch the reference itself makes
+        (model_utils.py:86).  Model and batch on different devices raise."""
         at = self.attn_layer
         bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
+        if host_ops.on_host(ids, vals, self.embedding.embedding.weight) and getattr(self, "_shard", None) is None:
+            z = host_ops.arm_block(self.variant == native.ONE_HEAD, ids, vals, self.embedding.embedding.weight, bw,
+                                   at.query, at.values, self.alpha, n_iter=self.n_iter)
+            y = self.arm_bn(z)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
+        _require_cuda(vals, "x['value']")
+        _require_cuda(ids, "x['id']")
+        _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
         needs_grad = torch.is_grad_enabled() and any(
             p.requires_grad for p in (self.embedding.embedding.weight, bw, at.query, at.values))
         if self.training or needs_grad:

@@ -22,7 +22,7 @@ The head's Linear + BatchNorm + ReLU passes are shared with ARM-Net (modules.py)
 import torch
 import torch.nn as nn
 
-from . import native
+from . import host_ops, native
 from .block import _require_cuda
 from .modules import HipBatchNorm1d, HipEmbedding, _LinearSplitKFn, _MLP
 
@@ -87,13 +87,20 @@ class SiblingBase(nn.Module):
         if vals is not None:
             x = {"id": x, "value": vals}
         ids, v = x["id"], x["value"]
-        _require_cuda(v, "x['value']")
-        _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
+        if not self._on_host(ids, v):
+            _require_cuda(v, "x['value']")
+            _require_cuda(ids, "x['id']")
+            _require_cuda(self.embedding.embedding.weight, "the model (call model.cuda())")
         if v.dtype != torch.float32:
             raise native.ArmnetNativeError(f"x['value'] must be float32, got {v.dtype}")
         v_run = v if v.is_contiguous() else v.contiguous()
         ids = ids if ids.is_contiguous() else ids.contiguous()
         return ids, v, v_run
+
+    def _on_host(self, ids, v):
+        """a model that was never moved to the GPU, called with host tensors: the reference's ATen op chain from this
+        module's own sub-modules (host_ops.py; the reference dispatches the same way, model_utils.py:86)"""
+        return host_ops.on_host(ids, v, self.embedding.embedding.weight)
 
     def _needs_autograd(self):
         """training mode, or eval mode with autograd on and a trainable parameter: the composed differentiable path"""
@@ -315,6 +322,13 @@ class GC_ARMModel(SiblingBase):
     def forward(self, x, vals=None):
         """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (gc_arm.py:82-105: squeeze(1))"""
         ids, v, v_run = self._inputs(x, vals)
+        if self._on_host(ids, v):                                                # gc_arm.py:86-94 on host tensors
+            host_ops.clamp_vals_(v_run)
+            x_emb = self.embedding({"id": ids, "value": v_run})
+            x_exp = self.emb_bn(torch.exp(x_emb))
+            arm = torch.einsum("bfe,bkof->bkoe", x_exp, self.attn_layers(x_emb))
+            arm = self.arm_bn(arm.reshape(arm.shape[0], -1, self.nemb))
+            return self._finish(arm, ids, v, v_run)
         if self._needs_autograd():
             return self._finish(self._arm_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.arm_block(ids, v_run), ids, v, v_run)
@@ -414,6 +428,11 @@ class AFNModel(SiblingBase):
         """x = {'id': Long[B,F], 'value': Float[B,F]} -> logits Float[B] (afn.py:49-72: squeeze(1))"""
         ids, v, v_run = self._inputs(x, vals)
         self.embedding_clip()
+        if self._on_host(ids, v):                                                # afn.py:56-69 on host tensors
+            host_ops.clamp_vals_(v_run)
+            x_log = self.emb_bn(torch.log(self.embedding({"id": ids, "value": v_run}))).transpose(1, 2)
+            afn = self.afn_bn(torch.exp(self.afn(x_log)).transpose(1, 2))
+            return self._finish(self.dropout(afn), ids, v, v_run)
         if self._needs_autograd():
             return self._finish(self._afn_block_autograd(ids, v_run), ids, v, v_run)
         return self._finish(self.afn_block(ids, v_run), ids, v, v_run)

@@ -149,16 +149,20 @@ def settle_clocks(fn, ms, cap_ms=None):
     100-116 us per step for the first ~2 s, 87 us from then on, same kernel).  The K timed steps are a few milliseconds, so
     without this they would measure the ramp of a cold device instead of the steady state of a serving loop.
 
-    Plateau (round-3 verdict, item 1): at least `ms` milliseconds AND the last 8 chunks of 64 steps within 1 % of each
-    other AND within 1 % of the fastest chunk seen so far (chunks timed by HIP events on the current stream: the host
-    clock around a 5 ms chunk is itself 1 % noisy).  "No new best for 8 chunks" — the round-3 rule — also holds on a clock
-    that is still creeping in steps smaller than 1 %.  Gives up after `cap_ms` (default 10 x ms).
+    Plateau (round-4 verdict, item 5): at least `ms` milliseconds AND the MEDIAN of the last 8 chunks of 64 steps within
+    1 % of the median of the 8 chunks before them AND within 1 % of the fastest such 8-chunk median seen so far (chunks
+    timed by HIP events on the current stream: the host clock around a 5 ms chunk is itself 1 % noisy).  Medians, because
+    single chunks on this device scatter by several per cent from one to the next (BENCH_r04: 5.8 % between windows,
+    which the round-4 rule — all of the last 8 chunks within 1 % of each other — could not reach in its 3 s cap); a clock
+    that is still creeping moves the 8-chunk median by more than 1 % per 8 chunks or it is not worth waiting for.
+    Gives up after `cap_ms` (default 10 x ms).
     Returns (chunks run, reached the plateau)."""
     if ms <= 0:
         return 0, True
     cap_ms = cap_ms if cap_ms is not None else 10 * ms
     t0 = time.perf_counter()
     chunks = []
+    best8 = float("inf")
     while True:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -168,13 +172,22 @@ def settle_clocks(fn, ms, cap_ms=None):
         torch.cuda.synchronize()
         chunks.append(e0.elapsed_time(e1))
         elapsed = (time.perf_counter() - t0) * 1e3
-        last = chunks[-8:]
-        flat = len(last) == 8 and max(last) <= 1.01 * min(last) and min(last) <= 1.01 * min(chunks)
+        flat = False
+        if len(chunks) >= 8:
+            m_last = median(chunks[-8:])
+            best8 = min(best8, m_last)
+            if len(chunks) >= 16:
+                m_prev = median(chunks[-16:-8])
+                flat = abs(m_last - m_prev) <= 0.01 * m_last and m_last <= 1.01 * best8
         done = (elapsed >= ms and flat) or elapsed >= cap_ms
         if AGREE[0] is not None:
             done = AGREE[0](done)                 # a step may hold collectives: every rank runs the same number of chunks
         if done:
+            SETTLE_NOISE[0] = (max(chunks[-8:]) - min(chunks[-8:])) / median(chunks[-8:]) if len(chunks) >= 8 else None
             return len(chunks), bool(elapsed >= ms and flat)
+
+
+SETTLE_NOISE = [None]         # (max - min) / median of the last 8 chunks of the latest settle_clocks call
 
 
 def median(xs):
@@ -237,76 +250,52 @@ def cpu_baseline(a, model, ids_cpu, vals_cpu):
     return out
 
 
-def aten_chain_block(variant, ids, vals, sd, alpha, n_iter=50):
-    """SURVEY §8d CPU baseline (i): the reference's ATen OP CHAIN for rows a2..a9 on CPU tensors — what `train.py:117`
-    executes when the model sits on the host — restated here from SURVEY §3.2-3.4's math (nothing of the reference
-    travels to the GPU box): in-place clamp, embedding x value, key projection, gates, 50-step bisection entmax with
-    tensor-tensor `pow` (softmax when alpha == 1), value weighting, einsum + exp, eval BatchNorm1d.  `sd` holds torch
-    CPU tensors under the reference's state_dict names.  Test infrastructure like the oracle: only this file's
-    cpu_baseline leg and tests/ call it (tests/test_bench_contract.py holds it to the golden vectors)."""
-    one = variant == "1h"
-    vals.clamp_(0.001, 1.0)                                                     # armnet_1h.py:81 / armnet.py:82
-    x = torch.nn.functional.embedding(ids, sd["embedding.embedding.weight"]) * vals.unsqueeze(2)    # layers.py:20-21
-    q = sd["attn_layer.query"]
-    if one:                                                                     # armnet_1h.py:30-32
-        keys = torch.nn.functional.linear(x, sd["attn_layer.bilinear_w.weight"])
-        gates = torch.einsum("bfe,oe->bof", keys, q) * q.shape[-1] ** -0.5
-    else:                                                                       # armnet.py:33-34
-        gates = torch.einsum("bfx,kxy,koy->bkof", x, sd["attn_layer.bilinear_w"], q) * q.shape[-1] ** -0.5
-    if alpha == 1.0:
-        p = torch.softmax(gates, dim=-1)
-    else:                                                                       # utils/entmax.py:29-68 (SURVEY §3.4)
-        d = gates.shape[-1]
-        al = torch.full((1,) * gates.dim(), alpha, dtype=gates.dtype).expand(*gates.shape[:-1], 1)
-        am1 = al - 1
-        inv = 1 / am1
-        X = gates * am1
-        mx = X.max(dim=-1, keepdim=True).values
-        tau_lo = mx - 1.0
-        tau_hi = mx - (1.0 / d) ** am1
-        f_lo = torch.clamp(X - tau_lo, min=0).pow(inv).sum(-1, keepdim=True) - 1
-        dm = tau_hi - tau_lo
-        for _ in range(n_iter):
-            dm = dm / 2
-            tau_m = tau_lo + dm
-            p = torch.clamp(X - tau_m, min=0).pow(inv)
-            f_m = p.sum(-1, keepdim=True) - 1
-            tau_lo = torch.where((f_m * f_lo) >= 0, tau_m, tau_lo)
-        p = p / p.sum(-1, keepdim=True)
-    v = sd["attn_layer.values"]
-    if one:
-        w = torch.einsum("bof,of->bof", p, v)                                   # armnet_1h.py:34
-        z = torch.exp(torch.einsum("bfe,bof->boe", x, w))                       # armnet_1h.py:85-86
+def host_twin(a, model):
+    """the same module, never moved to the GPU: constructor arguments of `build_model`, the device model's state_dict"""
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    nfeat = sd["embedding.embedding.weight"].shape[0]
+    ens = bool(getattr(a, "ensemble", False))
+    if a.nhead == 1:
+        from models.armnet_1h import ARMNetModel
+        m = ARMNetModel(a.nfield, nfeat, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, ens, 2, 256)
     else:
-        w = torch.einsum("bkof,kof->bkof", p, v)                                # armnet.py:36
-        z = torch.exp(torch.einsum("bfe,bkof->bkoe", x, w))                     # armnet.py:86-87
-        z = z.reshape(z.shape[0], -1, z.shape[-1])                              # armnet.py:88: 'b k o e -> b (k o) e'
-    return torch.nn.functional.batch_norm(z, sd["arm_bn.running_mean"], sd["arm_bn.running_var"], sd["arm_bn.weight"],
-                                          sd["arm_bn.bias"], False, 0.1, 1e-5)
+        from models.armnet import ARMNetModel
+        m = ARMNetModel(a.nfield, nfeat, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, ens, 2, 256)
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def aten_chain_block(host_model, ids, vals):
+    """SURVEY §8d CPU baseline (i): the reference's ATen OP CHAIN for rows a2..a9 on CPU tensors — what `train.py:117`
+    executes when the model sits on the host: the product module itself, never moved to the GPU, called with host
+    tensors (`armnet_hip/host_ops.py`: in-place clamp, embedding x value, key projection, gates, 50-step bisection entmax
+    with tensor-tensor `pow` (softmax when alpha == 1), value weighting, einsum + exp; then the eval-mode BatchNorm1d
+    module).  Held to the golden vectors by tests/test_host_tensors.py and tests/test_bench_contract.py."""
+    return host_model.arm_block(ids, vals)
 
 
 def cpu_baseline_aten(a, model, ids_cpu, vals_cpu, threads):
     """the op chain above on `threads` host threads, on the first n samples of the same batch (about a.cpu_seconds)"""
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    variant = "1h" if a.nhead == 1 else "mh"
+    host = host_twin(a, model)
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         n = min(a.batch, 2048)
         with torch.no_grad():
             t0 = time.perf_counter()
-            aten_chain_block(variant, ids_cpu[:n], vals_cpu[:n].clone(), sd, a.alpha)
+            aten_chain_block(host, ids_cpu[:n], vals_cpu[:n].clone())
             t_probe = time.perf_counter() - t0
             # size the sample so that it takes about cpu_seconds / 2 (the softmax branch is ~15x faster than bisection)
             n = int(max(n, min(a.batch, n * (a.cpu_seconds / 2) / max(t_probe, 1e-6)))) // 1024 * 1024 or n
             t0 = time.perf_counter()
-            aten_chain_block(variant, ids_cpu[:n], vals_cpu[:n].clone(), sd, a.alpha)
+            aten_chain_block(host, ids_cpu[:n], vals_cpu[:n].clone())
             t = time.perf_counter() - t0
     finally:
         torch.set_num_threads(old)
     return {"value": n / t, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 pass of the first {n} samples of the same batch through the reference's ATen op chain restated "
-                      f"in bench.py (embedding, Linear/einsum, {'softmax' if a.alpha == 1.0 else '50-step bisection entmax with tensor pow'}, "
+            "sample": f"1 pass of the first {n} samples of the same batch through the reference's ATen op chain — the product "
+                      f"module's own host-tensor branch (armnet_hip/host_ops.py: embedding, Linear/einsum, "
+                      f"{'softmax' if a.alpha == 1.0 else '50-step bisection entmax with tensor pow'}, "
                       f"einsum, exp, BatchNorm1d) on CPU tensors, torch.set_num_threads({threads})"}
 
 
@@ -484,7 +473,8 @@ def main():
                 # the same W + K steps from a cold device, for the record (`cold_start` in the line)
                 m["cold"] = window(step_block)[0]
             n_chunks, flat = settle_clocks(step_block, a.settle_ms, cap_ms=20 * a.settle_ms)
-            settle_info.update(chunks_of_64_steps=n_chunks, plateau_reached=flat)
+            settle_info.update(chunks_of_64_steps=n_chunks, plateau_reached=flat, cap_ms=20 * a.settle_ms,
+                               spread_of_last_8_chunks=SETTLE_NOISE[0])
             head_windows.append(("clock settle",) + window(step_block))
             m["block"] = None                             # filled from head_windows at the end
         else:
@@ -848,8 +838,12 @@ def main():
                                    f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read); every step of a window gets a "
                                    f"pristine (unclamped) copy of its values from a pool of {POOL} buffers restored before the "
                                    f"window, so the in-place clamp's write-back is live in the timed steps"
-                                   + ("" if a.warmup + a.steps <= POOL else f" (first {POOL} steps of a window only)") +
-                                   f"; device clocks settled to a plateau by >= {a.settle_ms:g} ms of the same step, untimed; "
+                                   + ("" if a.warmup + a.steps <= POOL else f" (first {POOL} steps of a window only)")
+                                   + ("; no clock-settling pre-run; " if a.settle_ms <= 0 else
+                                      f"; device clocks settled to a plateau by >= {a.settle_ms:g} ms of the same step, untimed; "
+                                      if settle_info.get("plateau_reached") else
+                                      f"; the clock-settling pre-run hit its {20 * a.settle_ms:g} ms cap WITHOUT reaching a "
+                                      f"plateau (see clock_settle); ") +
                                    f"value = median of {len(win_ms)} windows of {a.steps} steps spread over the process",
                        "global_batch": world * a.batch, "parallelism": parallelism, "clock_settle_ms": a.settle_ms,
                        "ids": a.ids},

@@ -73,13 +73,13 @@ def test_aten_chain_of_the_cpu_baseline_matches_the_reference_vectors():
     import torch
     import bench
     from golden_util import load
+    from model_util import build_model
     for name in ("g2_criteo_1h_a2.0_stress", "g2_criteo_1h_a1.7_stress", "g2_criteo_1h_a1.0_fresh", "g2_criteo_1h_a2.5_stress",
                  "g3_criteo_mh4_a1.7_stress", "g1_frappe_1h_a1.7_fresh"):
         meta, sd, ids, vals, ref = load(name)
-        sdt = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
         v = torch.from_numpy(vals.copy())
         with torch.no_grad():
-            out = bench.aten_chain_block(meta["variant"], torch.from_numpy(ids), v, sdt, float(meta["ctor"]["alpha"])).numpy()
+            out = bench.aten_chain_block(build_model(meta, sd), torch.from_numpy(ids), v).numpy()
         want = ref["x_arm"].reshape(out.shape)
         assert float(np.max(np.abs(out - want))) <= 1e-6 * max(1.0, float(np.max(np.abs(want)))), name
         np.testing.assert_array_equal(v.numpy(), ref["vals_clamped"])

@@ -136,26 +136,6 @@ def test_state_dict_round_trip(name):
         np.testing.assert_array_equal(v.numpy(), sd[k])
 
 
-def test_cpu_tensors_are_rejected_loudly():
-    """No CPU fallback: the product path refuses host tensors instead of computing elsewhere."""
-    from armnet_hip import native
-    meta, sd, ids, vals, _ = load("g7_odd_1h_f13_e12_h7_a1.5")
-    m = build_model(meta, sd)
-    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
-        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
-    from utils.entmax import entmax_bisect
-    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
-        entmax_bisect(torch.zeros(2, 5))
-
-
-def test_training_mode_also_refuses_cpu_tensors():
-    from armnet_hip import native
-    meta, sd, ids, vals, _ = load("g7_odd_1h_f13_e12_h7_a1.5")
-    m = build_model(meta, sd).train()
-    with pytest.raises(native.ArmnetNativeError, match="no CPU fallback"):
-        m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
-
-
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from armnet_hip import native
     monkeypatch.setattr(native, "_lib", None)

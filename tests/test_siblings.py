@@ -68,17 +68,6 @@ def test_product_module_has_the_reference_state_dict(name):
     assert list(m.state_dict().keys()) == list(sd.keys())
 
 
-def test_cpu_tensors_are_refused_loudly():
-    """no CPU fallback: a model or batch that is not on the GPU raises (training and inference alike)"""
-    from armnet_hip import native
-    meta, sd, ids, vals, _ = load("s2_afn_frappe_h10_ens_stress")
-    m = _build(meta, sd)
-    for mode in (True, False):
-        m.train(mode)
-        with pytest.raises(native.ArmnetNativeError):
-            m({"id": torch.from_numpy(ids), "value": torch.from_numpy(vals.copy())})
-
-
 GRAD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s3_grad_*.npz")))
 
 
