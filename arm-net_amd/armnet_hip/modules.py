@@ -335,7 +335,7 @@ class ArmNetBase(nn.Module):
                                  n_iter=self.n_iter, write_clamped_vals=True, check_ids=self.check_ids,
                                  flags=self.kernel_flags, out=out)
 
-    def shard_embedding(self, group=None, release_full=False):
+    def shard_embedding(self, group=None, release_full=False, hot_rows=0):
         """Row-shard the ARM embedding table over the process group (multi-GPU): this rank
         keeps a COPY of rows i = rank (mod world); every later inference arm_block() call fetches rows by
         all-to-all.  The full table must be resident when this is called.
@@ -345,14 +345,22 @@ class ArmNetBase(nn.Module):
         optimizer step: tracked by its storage pointer and version counter; writes through `.data` are not
         seen — call shard_embedding() again after those).  With release_full=True the parameter's storage is
         replaced by an empty [0, nemb] tensor afterwards — that is what frees the memory; the shard is then the
-        only copy (state_dict no longer holds the table)."""
+        only copy (state_dict no longer holds the table).
+
+        hot_rows = N (round 5): rows [0, N) — the head of a frequency-ordered id space, where skewed click logs put most
+        lookups — are also kept REPLICATED on every rank (N * nemb * 4 bytes) and served without crossing a link
+        (sharded.RowShardedTable).
+
+        Training with a row-sharded table is not supported (SURVEY.md §8e scopes the sharded lookup to inference: the
+        training-mode BatchNorm and the table gradient would need their own collectives): arm_block() raises
+        NotImplementedError in train mode / with autograd on while a shard is attached."""
         import torch.distributed as dist
         from .sharded import RowShardedTable, shard_rows
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         p = self.embedding.embedding.weight
         w = p.detach()
-        self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group)
+        self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group, hot_rows=hot_rows)
         self._shard_src = None if release_full else (p.data_ptr(), p._version)
         if release_full:
             p.data = torch.empty(0, w.shape[1], device=w.device, dtype=w.dtype)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
@@ -36,6 +36,7 @@ EXPORTS = (
     "armnet_afn_fused_bwd_supported", "armnet_afn_fused_bwd_f32", "armnet_bn_bwd_scatter_f32",
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
+    "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
 )
 
 _lib = None
@@ -563,23 +564,25 @@ def shard_route_fixed_ws_bytes(R, nfeat, dedup):
 
 
 def shard_route_fixed(n, ids, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, workspace=None, id_status=None,
-                      epoch=0):
+                      epoch=0, hot=(0, 0)):
     """routing of the fixed-capacity protocol in one call: send_pad [R*cap], perm_pad [n], counts [R], overflow flag.
     epoch (dedup only): 0 = the mark map is zeroed by the call; 2..255 = caller-managed mark epoch, no fill
-    (armnet_shard_route_fixed_epoch: valid after a call with epoch 0 or a smaller epoch on the same workspace)"""
+    (armnet_shard_route_fixed_epoch: valid after a call with epoch 0 or a smaller epoch on the same workspace).
+    hot = (hot_rows, hot_base): ids < hot_rows are replicated on every rank and not routed, perm_pad = hot_base + id
+    (armnet_shard_route_fixed_hot)"""
     _ids_ok(ids)
     _i32_ok(send_pad=send_pad, counts=counts, overflow=overflow)
     if perm_pad is not None:                 # None (dedup only): the position gather is left to shard_route_fixed_perm
         _i32_ok(perm_pad=perm_pad)
     with _on(ids, send_pad, perm_pad, counts, overflow, workspace, id_status):
-        check(load().armnet_shard_route_fixed_epoch(
+        check(load().armnet_shard_route_fixed_hot(
             ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), ctypes.c_int64(cap),
             int(bool(dedup)), _ptr(send_pad), _ptr(perm_pad), _ptr(counts), _ptr(overflow), _ptr(id_status),
             _ptr(workspace), ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
-            int(epoch), _stream()))
+            int(epoch), ctypes.c_int64(hot[0]), ctypes.c_int64(hot[1]), _stream()))
 
 
-def shard_gather_perm(idx, table, out, ids, R, nfeat, perm_pad, workspace):
+def shard_gather_perm(idx, table, out, ids, R, nfeat, perm_pad, workspace, hot=(0, 0)):
     """armnet_shard_gather_perm_f32: out[j] = table[idx[j]] and perm_pad[i] = position of ids[i] (workspace of a preceding
     shard_route_fixed(dedup=True, perm_pad=None)) in one launch"""
     _ids_ok(ids)
@@ -587,20 +590,22 @@ def shard_gather_perm(idx, table, out, ids, R, nfeat, perm_pad, workspace):
     if idx.dtype != torch.int32 or perm_pad.dtype != torch.int32:
         raise ArmnetNativeError("shard_gather_perm: idx and perm_pad must be int32")
     with _on(idx, table, out, ids, perm_pad, workspace):
-        check(load().armnet_shard_gather_perm_f32(ctypes.c_int64(idx.numel()), table.shape[1], _ptr(idx), _ptr(table),
-                                                  ctypes.c_int64(table.shape[0]), _ptr(out), ctypes.c_int64(ids.numel()),
-                                                  _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), _ptr(perm_pad),
-                                                  _ptr(workspace), ctypes.c_int64(workspace.numel()), _stream()))
+        check(load().armnet_shard_gather_perm_hot_f32(ctypes.c_int64(idx.numel()), table.shape[1], _ptr(idx), _ptr(table),
+                                                      ctypes.c_int64(table.shape[0]), _ptr(out), ctypes.c_int64(ids.numel()),
+                                                      _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), _ptr(perm_pad),
+                                                      _ptr(workspace), ctypes.c_int64(workspace.numel()),
+                                                      ctypes.c_int64(hot[0]), ctypes.c_int64(hot[1]), _stream()))
 
 
-def shard_route_fixed_perm(n, ids, R, nfeat, perm_pad, workspace):
+def shard_route_fixed_perm(n, ids, R, nfeat, perm_pad, workspace, hot=(0, 0)):
     """perm_pad[i] = position of id i's row, from the workspace a shard_route_fixed(dedup=True, perm_pad=None) call left"""
     _ids_ok(ids)
     _i32_ok(perm_pad=perm_pad)
     with _on(ids, perm_pad, workspace):
-        check(load().armnet_shard_route_fixed_perm(
+        check(load().armnet_shard_route_fixed_perm_hot(
             ctypes.c_int64(n), _ptr(ids), _id_type(ids), int(R), ctypes.c_int64(nfeat), _ptr(perm_pad), _ptr(workspace),
-            ctypes.c_int64(workspace.numel() * workspace.element_size()), _stream()))
+            ctypes.c_int64(workspace.numel() * workspace.element_size()), ctypes.c_int64(hot[0]), ctypes.c_int64(hot[1]),
+            _stream()))
 
 
 def shard_direct_perm(n, ids, R, nfeat, perm, id_status=None):

@@ -29,6 +29,14 @@ owners ship their shards as they are (ONE all_gather_into_tensor of ceil(nfeat /
 row exchange would move), no routing, no request exchange, no owner-side gather, and perm is the direct address
 (id % R) * L + id // R (armnet_shard_direct_perm).  The gathered buffer is transient; the table stays sharded at rest.
 
+Hot rows (round 5; SURVEY.md §8e's third lever, `RowShardedTable(hot_rows=N)`): click logs are skewed — in a
+frequency-ordered id space the first few ten thousand rows carry most lookups — so every rank also keeps rows [0, N)
+REPLICATED (N * E * 4 bytes: 4 MB for 64 k rows of 16 floats).  The routing kernels treat an id < N as already answered:
+it takes no slot and crosses no link, its perm entry points at row R * cap + id of the buffer the fused block reads — the
+received rows with the replicated hot rows appended — and the slots are sized for the COLD lookups only (agreed over the
+ranks like the step size).  The exact and whole-shard exchanges do not use the hot copy (every row also lives in its
+owner's shard), so the overflow fallback is unchanged.
+
 The arithmetic of the fused block is untouched: the sharded result is bit-equal to the single-GPU one.
 `ops` abstracts the two device kernels so that the routing logic can be exercised by world_size-2
 gloo tests on CPU with a test double (tests/test_sharded_gloo.py); the product default is HipShardOps.
@@ -68,8 +76,9 @@ class HipShardOps:
             native.shard_route_ids(n, ids_flat, R, nfeat, counts, send_local, perm, ws, id_status)
         return counts, send_local, perm
 
-    def gather(self, local_idx, table_local):
-        out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
+    def gather(self, local_idx, table_local, out=None):
+        if out is None:
+            out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
         if local_idx.numel():
             native.gather_scale(local_idx.numel(), table_local.shape[1], local_idx, None, table_local, out)
         return out
@@ -83,15 +92,17 @@ class HipShardOps:
         native.shard_pad_route(n, R, cap, counts, send_local, perm, send_pad, perm_pad, overflow)
         return send_pad, perm_pad
 
-    def gather_perm(self, local_idx, table_local, pending):
+    def gather_perm(self, local_idx, table_local, pending, out=None):
         """the owner-side gather AND the position gather a route_fixed(..., perm_with_gather=True) left pending, as one launch
         (armnet_shard_gather_perm_f32): -> rows [len(local_idx), E]; pending's perm_pad is filled in order on this stream"""
-        ids_flat, R, nfeat, perm_pad, ws = pending
-        out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
-        native.shard_gather_perm(local_idx, table_local, out, ids_flat, R, nfeat, perm_pad, ws)
+        ids_flat, R, nfeat, perm_pad, ws, hot = pending
+        if out is None:
+            out = torch.empty(local_idx.numel(), table_local.shape[1], device=table_local.device, dtype=torch.float32)
+        native.shard_gather_perm(local_idx, table_local, out, ids_flat, R, nfeat, perm_pad, ws, hot=hot)
         return out
 
-    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, defer_perm=False, perm_with_gather=False):
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, defer_perm=False, perm_with_gather=False,
+                    hot_rows=0):
         """-> send_pad [R*cap], perm_pad [n] (armnet_shard_route_fixed: routing of the fixed-capacity protocol in one call —
         one kernel without de-duplication; byte-map mark + chunk sums + emit, then one position gather, with it).
         overflow (int32[1]) |= 1 if a slot is too small.
@@ -100,24 +111,30 @@ class HipShardOps:
         with defer_perm that gather runs on a SIDE stream: it overlaps the index exchange / owner-side gather / row exchange
         that follow on the caller's stream.  perm_pad then carries the event the consumer HAS to wait for (`wait_perm`:
         sharded_arm_block does); the next route on this stream waits for it too, because the gather reads the workspace
-        the next route overwrites.  Without defer_perm (the default) everything is in order on the caller's stream."""
+        the next route overwrites.  Without defer_perm (the default) everything is in order on the caller's stream.
+        hot_rows: ids below it are replicated on every rank and not routed; their perm entry is R * cap + id."""
         n = ids_flat.numel()
         dev = ids_flat.device
+        hot = (int(hot_rows), R * cap)
         buf = torch.empty(R * cap + R, device=dev, dtype=torch.int32)      # counts right behind the slots: one fill for both
         send_pad, counts = buf[:R * cap], buf[R * cap:]
         perm_pad = torch.empty(n, device=dev, dtype=torch.int32)
         if not dedup:
-            native.shard_route_fixed(n, ids_flat, R, nfeat, cap, False, send_pad, perm_pad, counts, overflow, None, id_status)
+            native.shard_route_fixed(n, ids_flat, R, nfeat, cap, False, send_pad, perm_pad, counts, overflow, None, id_status,
+                                     hot=hot)
             return send_pad, perm_pad
         cur = torch.cuda.current_stream(dev)
         need = native.shard_route_fixed_ws_bytes(R, nfeat, True)
         key = (dev, cur.cuda_stream, "fixed")
         st = self._ws.get(key)
+        if st is not None and st["busy"] is not None:
+            # the previous step's position gather (side stream) still reads the workspace: wait BEFORE the workspace may be
+            # replaced below — the old block returns to the caching allocator with the dict (round-4 advisor finding)
+            cur.wait_event(st["busy"])
+            st["busy"] = None
         if st is None or st["ws"].numel() < need:
             st = self._ws[key] = {"ws": torch.empty(need, device=dev, dtype=torch.uint8), "side": torch.cuda.Stream(device=dev),
                                   "busy": None, "epoch": 0, "shape": None}
-        if st["busy"] is not None:
-            cur.wait_event(st["busy"])                 # the previous step's position gather still reads the workspace
         # mark epoch of the byte map: 0 (the call zeroes the map, marks are 1), then 2, 3, .., 255 without a fill, then 0 again;
         # a workspace that is new, or whose layout (R, nfeat) changed, starts over
         if st["shape"] != (R, nfeat):
@@ -129,24 +146,29 @@ class HipShardOps:
             epoch = st["epoch"]
             st["epoch"] = 2 if epoch == 0 else (epoch + 1 if epoch < 255 else 0)
         native.shard_route_fixed(n, ids_flat, R, nfeat, cap, True, send_pad, None, counts, overflow, st["ws"], id_status,
-                                 epoch=epoch)
+                                 epoch=epoch, hot=hot)
         if perm_with_gather:
             # the position gather rides in the owner-side gather's launch (gather_perm), in order on this stream
             st["busy"] = None
-            perm_pad._armnet_pending = (ids_flat, R, nfeat, perm_pad, st["ws"])
+            perm_pad._armnet_pending = (ids_flat, R, nfeat, perm_pad, st["ws"], hot)
             return send_pad, perm_pad
         if not (defer_perm and self.overlap_perm):
-            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"])
+            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"], hot=hot)
             st["busy"] = None
             return send_pad, perm_pad
         side = st["side"]
         side.wait_stream(cur)
+        capturing = torch.cuda.is_current_stream_capturing()
         with torch.cuda.stream(side):
-            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"])
-            st["busy"] = side.record_event()
+            native.shard_route_fixed_perm(n, ids_flat, R, nfeat, perm_pad, st["ws"], hot=hot)
+            ev = side.record_event()
+        # an event recorded inside a hipGraph capture must not be waited on by a later eager (or separately captured) call:
+        # the consumer of THIS step still gets it (same capture), the next route does not (round-4 advisor finding)
+        st["busy"] = None if capturing else ev
+        st["ws"].record_stream(side)
         ids_flat.record_stream(side)
         perm_pad.record_stream(side)
-        perm_pad._armnet_ready = st["busy"]
+        perm_pad._armnet_ready = ev
         return send_pad, perm_pad
 
     def direct_perm(self, ids_flat, R, nfeat, id_status=None):
@@ -164,7 +186,10 @@ def shard_rows(full_table, rank, world):
 class RowShardedTable:
     """One rank's shard of the embedding table + the lookup protocol above."""
 
-    def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto", protocol="fixed", capacity_factor=1.25):
+    def __init__(self, table_local, nfeat, group=None, ops=None, dedup="auto", protocol="fixed", capacity_factor=1.25,
+                 hot_rows=0):
+        self.hot_rows = 0         # rows [0, hot_rows) are ALSO replicated on every rank and never routed (set below)
+        self._hot_table = None    # [hot_rows, E], built lazily by one all-gather; dropped when the shard is re-cut
         self.protocol = protocol  # "fixed": equal-split exchanges, no host sync | "exact": data-dependent splits
         self.capacity_factor = float(capacity_factor)
         self._overflow = None     # device flag of the fixed protocol, OR-ed by every lookup since the last check
@@ -191,6 +216,9 @@ class RowShardedTable:
         expect = (self.nfeat - self.rank + self.world - 1) // self.world
         if table_local.shape[0] != expect:
             raise ValueError(f"rank {self.rank}: shard has {table_local.shape[0]} rows, expected {expect}")
+        if not 0 <= int(hot_rows) <= self.nfeat:
+            raise ValueError(f"hot_rows = {hot_rows} outside [0, nfeat = {self.nfeat}]")
+        self.hot_rows = int(hot_rows)
 
     @property
     def table_local(self):
@@ -202,6 +230,32 @@ class RowShardedTable:
         the whole-shard exchange all-gathers: it would otherwise keep serving the OLD rows (round-2 advisor finding)"""
         self._table_local = t
         self._table_ag = None
+        self._hot_table = None
+
+    def hot_table(self):
+        """rows [0, hot_rows) of the FULL table, replicated: every owner contributes its first ceil(hot_rows / R) local rows
+        (ids rank, rank + R, ...) to ONE all-gather, interleaved back into id order.  Built at the first lookup after the
+        shard was (re-)cut — a collective: the ranks re-cut together, as they do for any update of a sharded weight."""
+        if self._hot_table is None:
+            R, N = self.world, self.hot_rows
+            E = self._table_local.shape[1]
+            Lh = (N + R - 1) // R
+            mine = self._table_local[:Lh]
+            if mine.shape[0] < Lh:                     # a rank that owns one hot row less than the others: pad
+                mine = torch.cat([mine, mine.new_zeros(Lh - mine.shape[0], E)])
+            mine = mine.contiguous()
+            if R == 1 or not dist.is_initialized():
+                pieces = mine
+            elif self._via_host:
+                h = torch.empty(R * Lh, E, dtype=mine.dtype)
+                dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
+                pieces = h.to(mine.device)
+            else:
+                pieces = torch.empty(R * Lh, E, device=mine.device, dtype=mine.dtype)
+                dist.all_gather_into_tensor(pieces, mine, group=self.group)
+            # pieces[r * Lh + j] = row r + j * R  ->  id order
+            self._hot_table = pieces.view(R, Lh, E).transpose(0, 1).reshape(R * Lh, E)[:N].contiguous()
+        return self._hot_table
 
     def _agreed_lookups(self, n):
         """Lookups per step that slot size, de-duplication and the choice between the request-list and the whole-shard
@@ -235,6 +289,16 @@ class RowShardedTable:
                 m = int(t.item())
             self.slot_lookups = m
         return int(self.slot_lookups)
+
+    def _cold_lookups(self, flat):
+        """lookups of this step that the exchanges have to carry with hot rows replicated: n x the cold fraction, which is
+        MEASURED on the first lookup (one host read, where the step size is agreed anyway) and kept; later steps are
+        assumed to be drawn from the same distribution — a colder one overflows a slot and is repaired like any overflow"""
+        n = flat.numel()
+        if getattr(self, "_cold_frac", None) is None or self.slot_lookups is None:
+            cold = int((flat >= self.hot_rows).sum().item()) if n else 0
+            self._cold_frac = (cold / n) if n else 1.0
+        return max(1, int(self._cold_frac * n + 0.999999))
 
     def capacity(self, n, dedup):
         """slot size of the fixed protocol for n lookups: the mean n/R plus the slack factor and a few standard
@@ -297,7 +361,8 @@ class RowShardedTable:
             self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)
         # slot size, de-duplication and the exchange path are functions of the AGREED step size, not of this rank's
         # batch: every rank derives the same collectives from it whatever its own batch looks like
-        n_slot = self._agreed_lookups(n)
+        N = self.hot_rows
+        n_slot = self._agreed_lookups(self._cold_lookups(flat) if N else n)
         dedup = (8 * n_slot >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
         cap = self.capacity(n_slot, dedup)
         L = (self.nfeat + R - 1) // R
@@ -309,15 +374,19 @@ class RowShardedTable:
             # the slots directly (round 4): no back-to-back layout in between, no separate pad pass
             # the position gather on a side stream pays when there are exchanges to hide it behind; on one rank it only
             # competes with the owner-side gather for the memory system (measured: 182.5 us per step against 165.7 in order)
+            hot = {"hot_rows": N} if N else {}         # ids < N: replicated, not routed, perm = R * cap + id
             if defer_perm and R > 1 and isinstance(self.ops, HipShardOps):
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status,
-                                                          defer_perm=True)
+                                                          defer_perm=True, **hot)
             elif dedup and self.gather_with_perm and isinstance(self.ops, HipShardOps):
                 # in order on one stream: the position gather shares the owner-side gather's launch (their blocks overlap)
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status,
-                                                          perm_with_gather=True)
+                                                          perm_with_gather=True, **hot)
             else:
-                send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status)
+                send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status, **hot)
+        elif N:
+            raise native.ArmnetNativeError("hot_rows needs the fused fixed-protocol route (fused_route = True and an ops "
+                                           "object with route_fixed)")
         else:
             if n == 0:                                     # an empty slice still takes part in the exchanges
                 counts = torch.zeros(R, device=dev, dtype=torch.int32)
@@ -330,17 +399,28 @@ class RowShardedTable:
             send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
         E = self.table_local.shape[1]
         pending = getattr(perm_pad, "_armnet_pending", None)
-        gather = (lambda idx: self.ops.gather_perm(idx, self.table_local, pending)) if pending is not None else \
-                 (lambda idx: self.ops.gather(idx, self.table_local))
+        gather = (lambda idx, out=None: self.ops.gather_perm(idx, self.table_local, pending, out=out)) if pending is not None \
+            else (lambda idx, out=None: self.ops.gather(idx, self.table_local, out=out) if out is not None
+                  else self.ops.gather(idx, self.table_local))
         if pending is not None:
             del perm_pad._armnet_pending
+        # the buffer the fused block reads: R * cap received rows, then (hot_rows > 0) the replicated hot rows
+        hot = self.hot_table() if N else None
+        rows_in = torch.empty(R * cap + N, E, device=dev, dtype=torch.float32)
+        recv = rows_in[:R * cap]
         if R == 1 and not dist.is_initialized():
-            return gather(send_pad), perm_pad
-        recv_idx = torch.empty(R * cap, device=dev, dtype=torch.int32)
-        self._all_to_all(recv_idx, send_pad, None, None)
-        rows_out = gather(recv_idx)
-        rows_in = torch.empty(R * cap, E, device=dev, dtype=torch.float32)
-        self._all_to_all(rows_in, rows_out, None, None)
+            got = gather(send_pad, recv) if N else gather(send_pad)
+            if not N:
+                return got, perm_pad
+            if got.data_ptr() != recv.data_ptr():
+                recv.copy_(got)                        # (an ops object without `out` support)
+        else:
+            recv_idx = torch.empty(R * cap, device=dev, dtype=torch.int32)
+            self._all_to_all(recv_idx, send_pad, None, None)
+            rows_out = gather(recv_idx)
+            self._all_to_all(recv, rows_out, None, None)
+        if N:
+            rows_in[R * cap:].copy_(hot)               # N * E * 4 bytes per step (4 MB for 64 k rows of 16 floats)
         return rows_in, perm_pad
 
     def _lookup_whole_shards(self, flat, id_status=None):

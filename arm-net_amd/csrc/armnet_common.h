@@ -42,6 +42,8 @@ struct SparseMapCfg {
     float r;             // 1 / (alpha - 1)      (fp32, entmax.py:22)
     float tau_hi_off;    // (1/d) ** (alpha - 1) (entmax.py:47), also the mean-start offset
     float tau_tol;       // SOLVE_NEWTON (matrix-core forward): a row is also done once its Newton step is below this
+    float lin_tol;       // SOLVE_NEWTON / SOLVE_NEWTON15 (matrix-core forward): a Newton step below this is taken WITHOUT a
+                         // confirming evaluation, p following to first order (exactly at alpha = 1.5); see the kernel's solver loop
 };
 
 // Host: choose the solver the way armnet_hip.h documents.
@@ -56,6 +58,15 @@ inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_s
     // rule was measured); below, the tolerance shrinks with alpha - 1 so that the bound stays 3e-7 — alpha = 1.1 would
     // otherwise allow 2e-6 per element, a fifth of the parity bar (round-3 advisor finding)
     c.tau_tol = kNewtonTauTol * fminf(1.0f, c.am1 * (1.0f / 0.7f));
+    // first-order finish (round 5).  With step = d and r = 1 / (alpha - 1), per element: the tangent p - r t^(r-1) d misses
+    // (t - d)^r by at most 0.3 d^r where an element vanishes (t ~ r d) and by r (r - 1) d^2 / 2 for t near 1; both are held to
+    // 6e-7 / 2e-7 (the class of kNewtonTol / tau_tol): alpha = 1.7 -> 1.0e-4, 1.3 -> 2.3e-4, 1.1 -> 6.7e-5, 1.9 -> 7e-6.
+    // alpha = 1.5 recomputes (t - d)^2 exactly; only the unverified residual f'' d^2 / 2 <= nfield d^2 is left: 4e-7.
+    c.lin_tol = 0.f;
+    if (alpha > 1.0f && alpha < 2.0f) {
+        if (alpha == 1.5f) c.lin_tol = sqrtf(4e-7f / (float)(d > 0 ? d : 1));
+        else c.lin_tol = fminf(powf(2e-6f, c.am1), sqrtf(4e-7f / (c.r * (c.r - 1.0f))));
+    }
     if (alpha == 1.0f) {
         c.mode = SOLVE_SOFTMAX;
     } else if ((flags & ARMNET_F_FAITHFUL_BISECT) || alpha > 2.0f || alpha < 1.0f || n_iter < 24 || !ensure_sum_one) {

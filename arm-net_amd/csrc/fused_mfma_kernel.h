@@ -466,6 +466,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     const float invF = 1.0f / (float)F;
     const float tau_off = a.cfg.tau_hi_off;
     const float tau_tol = a.cfg.tau_tol;                  // generic alpha: step tolerance, scaled by alpha - 1 below 1.7
+    const float lin_tol = a.cfg.lin_tol;                  // generic alpha / 1.5: a step below this needs no confirming evaluation
     const float L2E = kLog2e;
 
     for (; grp < ngroups; grp += nwaves) {
@@ -760,6 +761,25 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     // which saves their recomputation in the weight pass
                     constexpr bool KEEP = (MODE == SOLVE_NEWTON) || ((MODE == SOLVE_MICHELOT || MODE == SOLVE_NEWTON15) && (WPS <= 3 || occ_keeps(E, NQ, SPW, WPS)));
                     f32x2 pkeep[KEEP ? SPW * NP : 1];
+                    // Round 5 — the last evaluation of a row only CONFIRMS a step that was already tiny.  Newton converges
+                    // quadratically from the left (trained-like weights, alpha = 1.7: f = 0.8, 0.13, 9e-3, 1.3e-4, 1.6e-7),
+                    // so once the step f / D is below `lin_tol` the threshold it leads to is final to O(step^2) and p there
+                    // is known to first order from what this evaluation already holds: p - r t^(r-1) step (clamped at 0;
+                    // alpha = 1.5: (t - step)^2 recomputed exactly).  Such a row leaves the loop with the step taken and the
+                    // correction PENDING; if other rows keep the wave going it is simply evaluated again (exactly) and the
+                    // correction is dropped; if the loop ends, one pass over the kept values applies it and sum(p) is the
+                    // Newton model's 1.  tools/solver_sim_r5.py: 5.23 -> 4.5 evaluations per pass at alpha = 1.7, 4.57 -> 3.8
+                    // at alpha = 1.5 (trained-like weights); random-init weights take one evaluation either way.
+#ifdef ARMNET_NO_LIN
+                    constexpr bool LIN = false;
+#else
+                    constexpr bool LIN = (MODE == SOLVE_NEWTON || MODE == SOLVE_NEWTON15);
+#endif
+                    constexpr bool LIN_GEN = LIN && MODE == SOLVE_NEWTON;
+                    f32x2 ukeep[LIN_GEN ? SPW * NP : 1];
+                    float dlin[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) dlin[s] = 0.f;
                     // A sample whose 16 rows have all converged leaves the loop on its own (wave-uniform masks on the scalar
                     // unit): with sparse supports the two samples of a group rarely finish in the same step.  Its tau, S and
                     // kept clamped differences are those of ITS last evaluation, which was at its final thresholds.
@@ -801,6 +821,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                                     sv = u * t;
                                     dv = u;
                                     pkeep[s * NP + jp] = sv;
+                                    if constexpr (LIN_GEN) ukeep[s * NP + jp] = u;
                                 }
                                 S2 = jp == 0 ? sv : S2 + sv;
                                 D2 = jp == 0 ? dv : D2 + dv;
@@ -824,7 +845,8 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                             if constexpr (MODE == SOLVE_NEWTON) Dv *= rr;
                             Ssum[s] = sd[0];
                             const float f = sd[0] - 1.0f;
-                            const float tn = fmaf(f, __builtin_amdgcn_rcpf(Dv), tau[s]);   // Newton self-corrects: 1-ulp rcp
+                            const float step = f * __builtin_amdgcn_rcpf(Dv);             // Newton self-corrects: 1-ulp rcp
+                            const float tn = tau[s] + step;
                             // A row is done when the residual OR — generic alpha — the Newton step f / D is small.  The step
                             // bounds the error of every p_i (|dp_i| <= r t_i^(r-1) |dtau| <= r |dtau|: 3e-7 at most); a DENSE
                             // row's residual, on the other hand, carries the rounding noise of its many terms (39 x
@@ -840,9 +862,39 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                             tau[s] = act ? tn : tau[s];
                             // two compare masks and a scalar AND (the ballot of the combined bool costs two more VALU ops)
                             live[s] = dbg_no_solve ? 0ull : (__builtin_amdgcn_ballot_w64(c_f) & __builtin_amdgcn_ballot_w64(c_t));
+                            if constexpr (LIN) {
+                                const bool c_l = step < lin_tol;                       // the step was taken; what it leads to is known
+                                dlin[s] = (act && c_l) ? step : 0.f;
+                                live[s] &= ~__builtin_amdgcn_ballot_w64(c_l);
+                            }
                             any_live |= live[s];
                         }
                         if (!any_live) break;
+                    }
+                    if constexpr (LIN) {
+#pragma unroll
+                        for (int s = 0; s < SPW; ++s) {
+                            if (__builtin_amdgcn_ballot_w64(dlin[s] != 0.f)) {          // wave-uniform: some row ended on a pending step
+                                if constexpr (LIN_GEN) {
+                                    const float k = -rr * dlin[s];                      // rows without a pending step: 0
+                                    const f32x2 k2 = {k, k};
+#pragma unroll
+                                    for (int jp = 0; jp < NP; ++jp) {
+                                        f32x2 pc;                                       // clamp: p in [0, 1]; the tangent of a vanishing element goes below 0
+                                        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(pc) : "v"(ukeep[s * NP + jp]), "v"(k2), "v"(pkeep[s * NP + jp]));
+                                        pkeep[s * NP + jp] = pc;
+                                    }
+                                } else if constexpr (KEEP) {                            // alpha = 1.5: p = (t - step)^2, exactly
+                                    tau2[s][0] = tau[s];
+#pragma unroll
+                                    for (int jp = 0; jp < NP; ++jp) {
+                                        const f32x2 t = pk_sub_clamp01_lo(XP_GET(s, jp), tau2[s]);
+                                        pkeep[s * NP + jp] = t * t;
+                                    }
+                                }                                                       // (not KEEP: the weight pass recomputes p from tau)
+                                Ssum[s] = dlin[s] != 0.f ? 1.0f : Ssum[s];              // the Newton model's sum at the new threshold
+                            }
+                        }
                     }
                     PHASE(3);
                     // unnormalised weights p * values (armnet_1h.py:34)

@@ -16,12 +16,17 @@
 // dedup = 1 — every DISTINCT id is a request (2.56 M uniform lookups of 1 M rows ask for 0.92 M rows).  Direct-address
 //   BYTE map over (owner, local) — measured (tools/ubench/route_mark.hip): 2.56 M byte stores into a 1 MB map 14 us,
 //   4-byte stores 32 us, atomicOr into a bitmap 98-124 us — then chunk sums, a one-block scan with a restart at every
-//   owner, and an emit pass that writes the slots and a COMPACT position table over the map itself: the byte of a marked
-//   id becomes its rank inside its 256-id group (one wave of the emit pass) and every group gets a 4-byte base, so
+//   owner, and an emit pass that writes the slots and a COMPACT position table of the map's shape BESIDE it (the map
+//   itself keeps the epoch of the last step that marked a position, see below): a marked id's byte of the `rank` array is
+//   its rank inside its 256-id group (one wave of the emit pass) and every group gets a 4-byte base, so
 //   perm_pad[i] = o * cap + base[p >> 8] + rank[p] is one 1-byte gather from a table of nfeat bytes (L2-resident; the
 //   4-byte table it replaces was 4 MB per million rows, written and gathered at 4x the traffic) plus a 4-byte one from
 //   a table 1/64 of that.  Requests inside a slot come out sorted by local row index (the owner-side gather walks its
 //   shard monotonically).
+//
+// Hot rows (round 5, SURVEY.md §8e's third lever): ids below `hot.rows` — the head of a frequency-ordered id space —
+// are replicated on every rank and never cross the links: such a lookup gets perm_pad[i] = hot.base + id (the caller
+// appends its replicated hot rows to the received buffer at row hot.base) and takes part in no slot, mark or count.
 #include "armnet_common.h"
 
 namespace armnet {
@@ -54,6 +59,12 @@ static OwnerMap make_owner_map(int R) {
     return m;
 }
 
+// the replicated head of the id space: ids < rows are served from row base + id of the consumer's buffer, never routed
+struct HotSet {
+    int64_t rows, base;
+    __device__ __forceinline__ bool has(uint32_t id) const { return (int64_t)id < rows; }
+};
+
 template <typename IdT>
 __device__ __forceinline__ uint32_t checked_id(const IdT* ids, int64_t i, int64_t nfeat, int32_t* id_status) {
     const uint64_t v = (uint64_t)(int64_t)ids[i];
@@ -65,7 +76,7 @@ __device__ __forceinline__ uint32_t checked_id(const IdT* ids, int64_t i, int64_
 // ---- dedup = 0 ------------------------------------------------------------------------------------------------------------
 template <typename IdT>
 __global__ void __launch_bounds__(RF_TPB)
-route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t cap,
+route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t cap, HotSet hot,
                    int32_t* __restrict__ send_pad, int32_t* __restrict__ perm_pad, int32_t* __restrict__ counts,
                    int32_t* overflow, int32_t* id_status) {
     __shared__ int hist[RF_MAX_R];
@@ -75,13 +86,20 @@ route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t 
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * (RF_TPB * RF_PER) + threadIdx.x;
     uint32_t owner[RF_PER], local[RF_PER];
-    int rank[RF_PER];
+    int rank[RF_PER];                                              // -1: a hot id (local[k] holds the id itself)
 #pragma unroll
     for (int k = 0; k < RF_PER; ++k) {
         const int64_t i = i0 + (int64_t)k * RF_TPB;
         if (i < n) {
-            om.split(checked_id(ids, i, nfeat, id_status), owner[k], local[k]);
-            rank[k] = atomicAdd(&hist[owner[k]], 1);               // LDS: unique rank of this lookup among the block's requests to that owner
+            const uint32_t id = checked_id(ids, i, nfeat, id_status);
+            if (hot.has(id)) {
+                local[k] = id;
+                owner[k] = 0;
+                rank[k] = -1;
+            } else {
+                om.split(id, owner[k], local[k]);
+                rank[k] = atomicAdd(&hist[owner[k]], 1);           // LDS: unique rank of this lookup among the block's requests to that owner
+            }
         }
     }
     __syncthreads();
@@ -92,6 +110,10 @@ route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t 
     for (int k = 0; k < RF_PER; ++k) {
         const int64_t i = i0 + (int64_t)k * RF_TPB;
         if (i < n) {
+            if (rank[k] < 0) {
+                perm_pad[i] = (int32_t)(hot.base + (int64_t)local[k]);
+                continue;
+            }
             const int64_t s = (int64_t)base[owner[k]] + rank[k];
             const int64_t slot0 = (int64_t)owner[k] * cap;
             if (s < cap) {
@@ -110,11 +132,13 @@ route_slots_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t 
 // position of an id in the (owner, local) order, owners padded to Lp (a multiple of RF_CHUNK) entries
 template <typename IdT>
 __global__ void __launch_bounds__(RF_TPB)
-uniq_mark_bytes_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+uniq_mark_bytes_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp, HotSet hot,
                        unsigned char* __restrict__ mark, unsigned char epoch, int32_t* id_status) {
     for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
         uint32_t o, l;
-        om.split(checked_id(ids, i, nfeat, id_status), o, l);
+        const uint32_t id = checked_id(ids, i, nfeat, id_status);
+        if (hot.has(id)) continue;                                  // replicated: asks nobody
+        om.split(id, o, l);
         mark[(int64_t)o * Lp + l] = epoch;
     }
 }
@@ -259,14 +283,19 @@ uniq_emit_kernel(int cpo, int64_t Lp, int64_t cap, const unsigned char* __restri
 
 template <typename IdT>
 __global__ void __launch_bounds__(RF_TPB)
-uniq_perm_pad_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+uniq_perm_pad_kernel(int64_t n, const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp, HotSet hot,
                      const unsigned char* __restrict__ rank, const int32_t* __restrict__ grp_base,
                      const int64_t* __restrict__ cap_in, int32_t* __restrict__ perm_pad) {
     const int64_t cap = *cap_in;
     for (int64_t i = (int64_t)blockIdx.x * RF_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RF_TPB) {
         const uint64_t v = (uint64_t)(int64_t)ids[i];
+        const uint32_t id = v >= (uint64_t)nfeat ? 0u : (uint32_t)v;
+        if (hot.has(id)) {
+            perm_pad[i] = (int32_t)(hot.base + (int64_t)id);
+            continue;
+        }
         uint32_t o, l;
-        om.split(v >= (uint64_t)nfeat ? 0u : (uint32_t)v, o, l);
+        om.split(id, o, l);
         const int64_t p = (int64_t)o * Lp + l;
         const int64_t sl = (int64_t)grp_base[p >> 8] + rank[p];
         perm_pad[i] = (int32_t)((int64_t)o * cap + (sl < cap ? sl : 0));   // overflow: a valid row, the wrong one (step repeated)
@@ -283,7 +312,7 @@ template <typename IdT, int W>
 __global__ void __launch_bounds__(RF_TPB)
 gather_rows_perm_kernel(int64_t n_rows, int EW, const int32_t* __restrict__ idx, const float* __restrict__ table,
                         int64_t table_rows, float* __restrict__ out, int gather_blocks, int perm_blocks, int64_t n,
-                        const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp,
+                        const IdT* __restrict__ ids, OwnerMap om, int64_t nfeat, int64_t Lp, HotSet hot,
                         const unsigned char* __restrict__ rank, const int32_t* __restrict__ grp_base,
                         const int64_t* __restrict__ cap_in, int32_t* __restrict__ perm_pad) {
     // block roles interleaved while both kinds last: even -> rows, odd -> positions
@@ -313,8 +342,13 @@ gather_rows_perm_kernel(int64_t n_rows, int EW, const int32_t* __restrict__ idx,
         const int64_t cap = *cap_in;
         for (int64_t i = (int64_t)role_idx * RF_TPB + threadIdx.x; i < n; i += (int64_t)perm_blocks * RF_TPB) {
             const uint64_t v = (uint64_t)(int64_t)ids[i];
+            const uint32_t id = v >= (uint64_t)nfeat ? 0u : (uint32_t)v;
+            if (hot.has(id)) {
+                perm_pad[i] = (int32_t)(hot.base + (int64_t)id);
+                continue;
+            }
             uint32_t o, l;
-            om.split(v >= (uint64_t)nfeat ? 0u : (uint32_t)v, o, l);
+            om.split(id, o, l);
             const int64_t p = (int64_t)o * Lp + l;
             const int64_t sl = (int64_t)grp_base[p >> 8] + rank[p];
             perm_pad[i] = (int32_t)((int64_t)o * cap + (sl < cap ? sl : 0));
@@ -337,8 +371,10 @@ size_t shard_route_fixed_ws_bytes(int R, int64_t nfeat, int dedup) {
 // armnet_shard_route_fixed(dedup = 1, perm_pad = NULL) left behind.  The request list (send_pad) does not depend on it, so
 // the caller may run it on a side stream beside the index exchange / owner-side gather (armnet_hip/sharded.py).
 int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
-                                  const void* ws, size_t ws_bytes, hipStream_t st) {
+                                  const void* ws, size_t ws_bytes, HotSet hot, hipStream_t st) {
     if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if (hot.rows < 0 || hot.rows > nfeat || hot.base < 0) return ARMNET_ERR_BAD_ARG;
+    if (hot.base + hot.rows >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     if (n == 0) return ARMNET_OK;
     const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
@@ -347,16 +383,18 @@ int launch_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R
     const int32_t* grp_base = reinterpret_cast<const int32_t*>(rank + P);
     const int64_t* cap_in = reinterpret_cast<const int64_t*>(grp_base + P / 256 + 2 * (P / RF_CHUNK));
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
-    if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, rank, grp_base, cap_in, perm_pad);
-    else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, rank, grp_base, cap_in, perm_pad);
+    if (id_type == ARMNET_ID_I64) uniq_perm_pad_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, hot, rank, grp_base, cap_in, perm_pad);
+    else uniq_perm_pad_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, hot, rank, grp_base, cap_in, perm_pad);
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;
 }
 
 int launch_shard_gather_perm(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows, float* out,
                              int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad, const void* ws,
-                             size_t ws_bytes, hipStream_t st) {
+                             size_t ws_bytes, HotSet hot, hipStream_t st) {
     if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if (hot.rows < 0 || hot.rows > nfeat || hot.base < 0) return ARMNET_ERR_BAD_ARG;
+    if (hot.base + hot.rows >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     if (n_rows == 0 && n == 0) return ARMNET_OK;
     const int64_t Lp = rf_Lp(R, nfeat), P = (int64_t)R * Lp;
     if (!ws || ws_bytes < shard_route_fixed_ws_bytes(R, nfeat, 1)) return ARMNET_ERR_BAD_ARG;
@@ -375,7 +413,7 @@ int launch_shard_gather_perm(int64_t n_rows, int E, const int32_t* idx, const fl
     if (n > 0 && pb < 1) pb = 1;
 #define ARMNET_GRP(IdT, W_) \
     gather_rows_perm_kernel<IdT, W_><<<gb + pb, RF_TPB, 0, st>>>(n_rows, EW, idx, table, table_rows, out, gb, pb, n, (const IdT*)ids, \
-                                                              om, nfeat, Lp, rank, grp_base, cap_in, perm_pad)
+                                                              om, nfeat, Lp, hot, rank, grp_base, cap_in, perm_pad)
     if (id_type == ARMNET_ID_I64) { if (W == 4) ARMNET_GRP(int64_t, 4); else if (W == 2) ARMNET_GRP(int64_t, 2); else ARMNET_GRP(int64_t, 1); }
     else { if (W == 4) ARMNET_GRP(int32_t, 4); else if (W == 2) ARMNET_GRP(int32_t, 2); else ARMNET_GRP(int32_t, 1); }
 #undef ARMNET_GRP
@@ -385,8 +423,10 @@ int launch_shard_gather_perm(int64_t n_rows, int E, const int32_t* idx, const fl
 
 int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow, int32_t* id_status,
-                             void* ws, size_t ws_bytes, int epoch, hipStream_t st) {
+                             void* ws, size_t ws_bytes, int epoch, HotSet hot, hipStream_t st) {
     if (R < 1 || R > RF_MAX_R) return ARMNET_ERR_UNSUPPORTED;
+    if (hot.rows < 0 || hot.rows > nfeat || hot.base < 0) return ARMNET_ERR_BAD_ARG;
+    if (hot.base + hot.rows >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     if ((int64_t)R * cap >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) || nfeat >= ((int64_t)1 << 32)) return ARMNET_ERR_UNSUPPORTED;
     const OwnerMap om = make_owner_map(R);
     if (!dedup) {
@@ -401,9 +441,9 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
         if (n == 0) return ARMNET_OK;
         const int64_t grid = (n + RF_TPB * RF_PER - 1) / (RF_TPB * RF_PER);
         if (id_type == ARMNET_ID_I64)
-            route_slots_kernel<int64_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, cap, send_pad, perm_pad, counts, overflow, id_status);
+            route_slots_kernel<int64_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, cap, hot, send_pad, perm_pad, counts, overflow, id_status);
         else
-            route_slots_kernel<int32_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, cap, send_pad, perm_pad, counts, overflow, id_status);
+            route_slots_kernel<int32_t><<<(int)grid, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, cap, hot, send_pad, perm_pad, counts, overflow, id_status);
         ARMNET_LAUNCH_CHECK();
         return ARMNET_OK;
     }
@@ -424,8 +464,8 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
     const uint32_t e4 = 0x01010101u * ep;
     const int gn = (int)((n + RF_TPB - 1) / RF_TPB < 4096 ? (n + RF_TPB - 1) / RF_TPB : 4096);
     if (n > 0) {
-        if (id_type == ARMNET_ID_I64) uniq_mark_bytes_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, mark, ep, id_status);
-        else uniq_mark_bytes_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, mark, ep, id_status);
+        if (id_type == ARMNET_ID_I64) uniq_mark_bytes_kernel<int64_t><<<gn, RF_TPB, 0, st>>>(n, (const int64_t*)ids, om, nfeat, Lp, hot, mark, ep, id_status);
+        else uniq_mark_bytes_kernel<int32_t><<<gn, RF_TPB, 0, st>>>(n, (const int32_t*)ids, om, nfeat, Lp, hot, mark, ep, id_status);
         ARMNET_LAUNCH_CHECK();
     }
     uniq_chunk_sums_kernel<<<(int)nchunk, RF_TPB, 0, st>>>(mark, e4, sums);
@@ -439,7 +479,7 @@ int launch_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int
         uniq_emit_kernel<false><<<(int)nchunk, RF_TPB, 0, st>>>(cpo, Lp, cap, mark, e4, rank, base, counts, send_pad, grp_base, cap_out, overflow);
     }
     ARMNET_LAUNCH_CHECK();
-    if (perm_pad) return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, ws, ws_bytes, st);
+    if (perm_pad) return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, ws, ws_bytes, hot, st);
     return ARMNET_OK;                         // perm_pad == NULL: the caller runs armnet_shard_route_fixed_perm itself
 }
 
@@ -460,7 +500,7 @@ extern "C" int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type,
         return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
-                                    workspace, (size_t)ws_bytes, 0, (hipStream_t)stream);
+                                    workspace, (size_t)ws_bytes, 0, HotSet{0, 0}, (hipStream_t)stream);
 }
 
 // The same with a caller-managed MARK EPOCH for the de-duplicating route (dedup != 0): epoch 0 = armnet_shard_route_fixed
@@ -475,14 +515,53 @@ extern "C" int armnet_shard_route_fixed_epoch(int64_t n, const void* ids, int id
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     if (epoch < 0 || epoch == 1 || epoch > 255) return ARMNET_ERR_BAD_ARG;
     return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
-                                    workspace, (size_t)ws_bytes, epoch, (hipStream_t)stream);
+                                    workspace, (size_t)ws_bytes, epoch, HotSet{0, 0}, (hipStream_t)stream);
+}
+
+// Round 5 — hot-row replication (SURVEY.md §8e's third lever): ids < hot_rows (the head of a frequency-ordered id space) are
+// held by every rank and never routed: perm_pad[i] = hot_base + id for them (the caller places its replicated hot rows at row
+// hot_base of the buffer the fused block reads — sharded.py: right behind the R * cap received rows), they take no slot, no
+// mark, no count.  hot_rows = 0 is armnet_shard_route_fixed_epoch.  The position gather that follows a dedup route with
+// perm_pad = NULL must be given the same (hot_rows, hot_base): armnet_shard_route_fixed_perm_hot / armnet_shard_gather_perm_hot_f32.
+extern "C" int armnet_shard_route_fixed_hot(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap,
+                                            int dedup, int32_t* send_pad, int32_t* perm_pad, int32_t* counts,
+                                            int32_t* overflow, int32_t* id_status, void* workspace, int64_t ws_bytes,
+                                            int epoch, int64_t hot_rows, int64_t hot_base, void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || cap < 1 || !send_pad || !counts || !overflow || (n > 0 && (!ids || (!perm_pad && !dedup))))
+        return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (epoch < 0 || epoch == 1 || epoch > 255) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_route_fixed(n, ids, id_type, R, nfeat, cap, dedup, send_pad, perm_pad, counts, overflow, id_status,
+                                    workspace, (size_t)ws_bytes, epoch, HotSet{hot_rows, hot_base}, (hipStream_t)stream);
+}
+
+extern "C" int armnet_shard_route_fixed_perm_hot(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
+                                                 const void* workspace, int64_t ws_bytes, int64_t hot_rows, int64_t hot_base,
+                                                 void* stream) {
+    if (n < 0 || R < 1 || nfeat <= 0 || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, workspace, (size_t)ws_bytes,
+                                         HotSet{hot_rows, hot_base}, (hipStream_t)stream);
+}
+
+extern "C" int armnet_shard_gather_perm_hot_f32(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows,
+                                                float* out, int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                                                int32_t* perm_pad, const void* workspace, int64_t ws_bytes, int64_t hot_rows,
+                                                int64_t hot_base, void* stream) {
+    if (n_rows < 0 || n < 0 || E <= 0 || R < 1 || nfeat <= 0 || table_rows <= 0) return ARMNET_ERR_BAD_ARG;
+    if ((n_rows > 0 && (!idx || !table || !out)) || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
+    if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
+    if (n_rows * (int64_t)E >= ((int64_t)1 << 40)) return ARMNET_ERR_UNSUPPORTED;
+    return launch_shard_gather_perm(n_rows, E, idx, table, table_rows, out, n, ids, id_type, R, nfeat, perm_pad, workspace,
+                                    (size_t)ws_bytes, HotSet{hot_rows, hot_base}, (hipStream_t)stream);
 }
 
 extern "C" int armnet_shard_route_fixed_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
                                              const void* workspace, int64_t ws_bytes, void* stream) {
     if (n < 0 || R < 1 || nfeat <= 0 || (n > 0 && (!ids || !perm_pad))) return ARMNET_ERR_BAD_ARG;
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
-    return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, workspace, (size_t)ws_bytes, (hipStream_t)stream);
+    return launch_shard_route_fixed_perm(n, ids, id_type, R, nfeat, perm_pad, workspace, (size_t)ws_bytes, HotSet{0, 0},
+                                         (hipStream_t)stream);
 }
 
 // the owner-side gather out[j, :] = table[idx[j], :] (idx: int32 local row indices of a request list; out-of-range -> row 0)
@@ -495,5 +574,5 @@ extern "C" int armnet_shard_gather_perm_f32(int64_t n_rows, int E, const int32_t
     if (id_type != ARMNET_ID_I64 && id_type != ARMNET_ID_I32) return ARMNET_ERR_BAD_ARG;
     if (n_rows * (int64_t)E >= ((int64_t)1 << 40)) return ARMNET_ERR_UNSUPPORTED;
     return launch_shard_gather_perm(n_rows, E, idx, table, table_rows, out, n, ids, id_type, R, nfeat, perm_pad, workspace,
-                                    (size_t)ws_bytes, (hipStream_t)stream);
+                                    (size_t)ws_bytes, HotSet{0, 0}, (hipStream_t)stream);
 }

@@ -28,9 +28,15 @@
 extern "C" {
 #endif
 
-/* 2: round-2 additions (prediction head, GC-ARM / AFN entry points, fixed-capacity and whole-shard routing helpers);
- * everything of version 1 is unchanged */
-#define ARMNET_ABI_VERSION 4
+/* History (every version only ADDS entry points; nothing that was exported ever changed its signature):
+ *   1  round 1: fold, fused forward / backward, lookup, entmax, BatchNorm passes, exact-protocol routing
+ *   2  round 2: prediction head, GC-ARM / AFN forward entry points, fixed-capacity and whole-shard routing helpers
+ *   3  round 3: siblings' training helpers (entmax backward, linear_small), wide heads
+ *   4  round 4: armnet_shard_route_fixed(_perm, _epoch), armnet_shard_gather_perm_f32, GC-ARM / AFN fused backward,
+ *               armnet_gather_map_stats_f32, armnet_bn_bwd_scatter_f32
+ *   5  round 5: hot-row replication of the row-sharded lookup (armnet_shard_route_fixed_hot, _perm_hot,
+ *               armnet_shard_gather_perm_hot_f32) */
+#define ARMNET_ABI_VERSION 5
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
@@ -307,6 +313,27 @@ int armnet_shard_route_fixed_epoch(int64_t n, const void* ids, int id_type, int 
 int armnet_shard_route_fixed(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
                              int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
                              int32_t* id_status, void* workspace, int64_t ws_bytes, void* stream);
+/*
+ * Hot-row replication (round 5; SURVEY.md §8e names it as the third lever for the 8-GPU target, the reference is
+ * single-device: no counterpart).  Real click logs are skewed: the head of a frequency-ordered id space carries most
+ * lookups.  Every rank keeps rows [0, hot_rows) replicated; the routing then treats an id < hot_rows as already
+ * answered: perm_pad[i] = hot_base + id, no slot entry, no mark, no count, nothing on the links.  The caller places
+ * its hot rows at row hot_base of the buffer the fused block reads (armnet_hip/sharded.py: right behind the R * cap
+ * received rows, hot_base = R * cap).  hot_rows = 0 is armnet_shard_route_fixed_epoch.  Everything else — arguments,
+ * overflow / id_status flags, epochs, NULL perm_pad with dedup — as armnet_shard_route_fixed_epoch; the position gather
+ * left pending by perm_pad = NULL must be given the same (hot_rows, hot_base).
+ */
+int armnet_shard_route_fixed_hot(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int64_t cap, int dedup,
+                                 int32_t* send_pad, int32_t* perm_pad, int32_t* counts, int32_t* overflow,
+                                 int32_t* id_status, void* workspace, int64_t ws_bytes, int epoch, int64_t hot_rows,
+                                 int64_t hot_base, void* stream);
+int armnet_shard_route_fixed_perm_hot(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm_pad,
+                                      const void* workspace, int64_t ws_bytes, int64_t hot_rows, int64_t hot_base,
+                                      void* stream);
+int armnet_shard_gather_perm_hot_f32(int64_t n_rows, int E, const int32_t* idx, const float* table, int64_t table_rows,
+                                     float* out, int64_t n, const void* ids, int id_type, int R, int64_t nfeat,
+                                     int32_t* perm_pad, const void* workspace, int64_t ws_bytes, int64_t hot_rows,
+                                     int64_t hot_base, void* stream);
 
 /*
  * Whole-shard exchange of the row-sharded lookup (csrc/shard_pad.hip): when a batch asks for most of every shard the

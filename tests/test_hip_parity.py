@@ -629,6 +629,52 @@ def test_shard_route_fixed_kernel_contract(R, dedup, cap_factor, dtype, nfeat, n
     assert int(status.item()) == 1
 
 
+@pytest.mark.parametrize("R,dedup,dtype,nfeat,n,hot", [
+    (8, False, torch.int64, 1_000_000, 39 * 8192, 65536), (8, True, torch.int64, 1_000_000, 39 * 8192, 65536),
+    (3, True, torch.int32, 5003, 39 * 811, 700), (2, False, torch.int32, 50021, 39 * 641, 1), (1, True, torch.int64, 5003, 4099, 5003),
+    (4, False, torch.int64, 50021, 39 * 641, 50021), (8, True, torch.int64, 100_000_000, 39 * 8192, 1 << 20)])
+def test_shard_route_fixed_hot_rows_contract(R, dedup, dtype, nfeat, n, hot):
+    """armnet_shard_route_fixed_hot (round 5): ids below hot_rows are replicated on every rank — perm_pad = R * cap + id for
+    them, no slot entry, no count; the cold ids keep the contract of armnet_shard_route_fixed exactly (the same slots as
+    routing the cold ids alone would give, up to positions inside a slot); all three forms of the position gather agree"""
+    from armnet_hip.sharded import HipShardOps, wait_perm
+    u = torch.rand(n, generator=torch.Generator().manual_seed(R + hot), dtype=torch.float64)
+    ids = (nfeat ** u - 1).clamp_(0, nfeat - 1).to(dtype)               # bench.py's skewed stream
+    ids[:3] = torch.tensor([0, max(hot - 1, 0), min(hot, nfeat - 1)]).to(dtype)
+    ops = HipShardOps()
+    idn = ids.numpy().astype(np.int64)
+    cold = idn >= hot
+    owner, local = idn % R, idn // R
+    c = (np.array([np.unique(local[cold & (owner == o)]).size for o in range(R)]) if dedup
+         else np.bincount(owner[cold], minlength=R))
+    cap = int(c.max()) + 16
+    overflow = torch.zeros(1, device=DEV, dtype=torch.int32)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    idd = ids.to(DEV)
+    send_pad, perm_pad = ops.route_fixed(idd, R, nfeat, cap, dedup, overflow, status, hot_rows=hot)
+    assert int(status.item()) == 0 and int(overflow.item()) == 0
+    sp, pp = send_pad.cpu().numpy(), perm_pad.cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(pp[~cold], R * cap + idn[~cold])         # hot: straight into the appended hot rows
+    np.testing.assert_array_equal(pp[cold] // cap, owner[cold])             # cold: a slot of the id's owner ...
+    np.testing.assert_array_equal(sp[pp[cold]], local[cold])                # ... that asks for the id's row
+    for o in range(R):
+        used = sp[o * cap: (o + 1) * cap]
+        assert (used[c[o]:] == 0).all()                                     # hot ids took no slot entry
+        if dedup:
+            assert (np.diff(used[:c[o]]) > 0).all()
+    if dedup:
+        assert np.unique(pp[cold]).size == sum(c)
+        for kw in ({"defer_perm": True}, {"perm_with_gather": True}):       # the other two forms of the position gather
+            sp1, pp1 = ops.route_fixed(idd, R, nfeat, cap, True, overflow, status, hot_rows=hot, **kw)
+            pend = getattr(pp1, "_armnet_pending", None)
+            if pend is not None:
+                ops.gather_perm(sp1, torch.zeros(max(int(local.max()) + 1, 1), 4, device=DEV), pend)
+            wait_perm(pp1)
+            assert torch.equal(sp1, send_pad) and torch.equal(pp1, perm_pad), kw
+    else:
+        assert np.unique(pp[cold]).size == int(cold.sum())
+
+
 @pytest.mark.parametrize("R,dtype", [(1, torch.int64), (8, torch.int32), (3, torch.int64)])
 def test_position_gather_on_a_side_stream_gives_the_in_order_result(R, dtype):
     """armnet_shard_route_fixed(perm_pad = NULL) + armnet_shard_route_fixed_perm on a side stream (what ranks > 1 do beside

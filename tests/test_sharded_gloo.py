@@ -35,8 +35,12 @@ class NumpyShardOps:
         send_local = (ids[order] // R).astype(np.int32)
         return torch.from_numpy(counts), torch.from_numpy(send_local), torch.from_numpy(perm)
 
-    def gather(self, local_idx, table_local):
-        return table_local[local_idx.long()].contiguous()
+    def gather(self, local_idx, table_local, out=None):
+        got = table_local[local_idx.long()].contiguous()
+        if out is not None:
+            out.copy_(got)
+            return out
+        return got
 
     def direct_perm(self, ids_flat, R, nfeat, id_status=None):
         """contract of armnet_shard_direct_perm: address of the row in the all-gathered (padded) shards"""
@@ -44,15 +48,18 @@ class NumpyShardOps:
         L = (nfeat + R - 1) // R
         return torch.from_numpy(((ids % R) * L + ids // R).astype(np.int32))
 
-    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None):
-        """contract of armnet_shard_route_fixed: the slots directly; positions inside a slot are ANY unique assignment
-        (here: reversed arrival order without de-duplication, sorted by local index with it)"""
+    def route_fixed(self, ids_flat, R, nfeat, cap, dedup, overflow, id_status=None, hot_rows=0):
+        """contract of armnet_shard_route_fixed(_hot): the slots directly; positions inside a slot are ANY unique assignment
+        (here: reversed arrival order without de-duplication, sorted by local index with it); ids < hot_rows take no slot
+        and point at row R * cap + id"""
         ids = ids_flat.numpy().astype(np.int64)
         owner, local = ids % R, ids // R
         send_pad = np.zeros(R * cap, np.int32)
         perm_pad = np.empty(ids.size, np.int32)
+        hot = ids < hot_rows
+        perm_pad[hot] = (R * cap + ids[hot]).astype(np.int32)
         for o in range(R):
-            sel = np.nonzero(owner == o)[0]
+            sel = np.nonzero((owner == o) & ~hot)[0]
             if dedup:
                 u, inv = np.unique(local[sel], return_inverse=True)
                 slot = inv
@@ -342,3 +349,90 @@ def test_bad_id_on_one_rank_is_seen_by_every_rank_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, False, True), (1, False, True)], res
+
+
+# ---- round 5: hot-row replication (SURVEY.md 8e's third lever) -----------------------------------------------------------
+
+def _zipf_ids(nfeat, shape, seed):
+    """bench.py's skewed id stream: log-uniform over [0, nfeat) — the head of the id space carries most lookups"""
+    u = torch.rand(*shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+    return (nfeat ** u - 1).clamp_(0, nfeat - 1).to(torch.int64)
+
+
+def _hot_worker(rank, world, port, q, dedup, hot_rows):
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from armnet_hip.sharded import RowShardedTable, shard_rows
+        nfeat, E, B, F = 20011, 8, 97, 6
+        old = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(7))
+        new = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(8))
+        ids = _zipf_ids(nfeat, (B, F), 100 + rank)
+        ids[0, :4] = torch.tensor([0, hot_rows - 1, hot_rows, nfeat - 1])          # both sides of the hot boundary
+        out = {}
+        for name, hr in (("cold", 0), ("hot", hot_rows)):
+            shard = RowShardedTable(shard_rows(old, rank, world), nfeat, None, ops=NumpyShardOps(), dedup=dedup,
+                                    protocol="fixed", hot_rows=hr)
+            shard.whole_shard = False
+            rows, perm = shard.lookup(ids)
+            ok = bool(torch.equal(rows[perm.long()].view(B, F, E), old[ids]))
+            over = shard.overflowed()
+            cap_rows = int(rows.shape[0]) - hr                                     # R * cap: what the row exchange carries
+            # a step with FEWER hot ids than the first one: may overflow (flagged on every rank), repaired exactly
+            ids2 = torch.randint(0, nfeat, (B, F), generator=torch.Generator().manual_seed(200 + rank))
+            rows2, perm2 = shard.lookup(ids2)
+            over2 = shard.overflowed()
+            if over2:
+                rows2, perm2 = shard.lookup(ids2, protocol="exact")
+            ok2 = bool(torch.equal(rows2[perm2.long()].view(B, F, E), old[ids2]))
+            # re-cut shard (weight update): the hot copy must follow
+            shard.table_local = shard_rows(new, rank, world)
+            rows3, perm3 = shard.lookup(ids)
+            ok3 = bool(torch.equal(rows3[perm3.long()].view(B, F, E), new[ids]))
+            out[name] = (ok, over, cap_rows, ok2, ok3, shard.last_path)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dedup", [(2, False), (2, True), (3, False)])
+def test_hot_rows_are_served_locally_and_shrink_the_exchange_gloo(world, dedup):
+    """RowShardedTable(hot_rows=N): rows[perm] still reproduces table[ids] bit for bit (ids on both sides of the hot
+    boundary, duplicates, a colder second step, a re-cut shard), the hot ids take no slot, and the slots — what the row
+    exchange carries — shrink with the cold fraction of the skewed stream (>= 3x here)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + os.getpid() % 2000 + 3 * world + dedup
+    procs = [ctx.Process(target=_hot_worker, args=(r, world, port, q, dedup, 2048)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    for rank, out in res:
+        for name in ("cold", "hot"):
+            ok, over, cap_rows, ok2, ok3, path = out[name]
+            assert ok and ok2 and ok3 and not over and path in ("fixed", "exact"), (rank, name, out)
+    assert len({out["hot"][2] for _, out in res}) == 1                  # the same slot size on every rank
+    cold_rows, hot_rows_ = res[0][1]["cold"][2], res[0][1]["hot"][2]
+    assert hot_rows_ * 3 <= cold_rows, (cold_rows, hot_rows_)
+
+
+def test_hot_rows_on_one_rank_without_a_process_group():
+    """world 1, no torch.distributed: the gather writes straight into the front of the consumer's buffer"""
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    from armnet_hip.sharded import RowShardedTable
+    nfeat, E = 5003, 4
+    table = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(1))
+    ids = _zipf_ids(nfeat, (50, 7), 3)
+    for dedup in (False, True):
+        shard = RowShardedTable(table.clone(), nfeat, None, ops=NumpyShardOps(), dedup=dedup, hot_rows=512)
+        shard.whole_shard = False
+        rows, perm = shard.lookup(ids)
+        assert torch.equal(rows[perm.long()].view(50, 7, E), table[ids])
+        assert torch.equal(rows[-512:], table[:512]) and not shard.overflowed()
+    with pytest.raises(ValueError):
+        RowShardedTable(table, nfeat, None, ops=NumpyShardOps(), hot_rows=nfeat + 1)

@@ -294,3 +294,93 @@ def test_sharded_lookup_through_rccl_at_world_size_one():
     assert res["whole_shards"] == (True, "whole_shards"), res
     assert res["fixed"] == (True, "fixed") and res["fixed_nodedup"] == (True, "fixed") and res["exact"] == (True, "exact"), res
     assert res["bad_id"][0], res
+
+
+# ---- round 5: hot-row replication ----------------------------------------------------------------------------------------
+
+def _zipf(nfeat, shape, g):
+    u = torch.rand(*shape, generator=g, dtype=torch.float64)
+    return (nfeat ** u - 1).clamp_(0, nfeat - 1).to(torch.int64)
+
+
+def _worker_hot(rank, world, port, dedup, micro, q):
+    for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from golden_util import load
+        from model_util import build_model
+        dev = "cuda:0"
+        meta, sd, _, _, _ = load("g2_criteo_1h_a2.0_stress")
+        c = meta["ctor"]
+        g = torch.Generator().manual_seed(60 + rank)
+        B, hot = 333, 512
+        ids = _zipf(c["nfeat"], (B, c["nfield"]), g)
+        ids[0, :4] = torch.tensor([0, hot - 1, hot, c["nfeat"] - 1])      # both sides of the hot boundary
+        ids[1, :] = ids[1, 0]
+        vals = torch.rand(B, c["nfield"], generator=g)
+        m = build_model(meta, sd, dev)
+        with torch.no_grad():
+            want = m.arm_block(ids.to(dev), vals.clone().to(dev))
+            m.shard_embedding(hot_rows=hot)
+            m._shard.dedup, m._shard.micro_batches, m._shard.whole_shard = dedup, micro, False
+            got = m.arm_block(ids.to(dev), vals.clone().to(dev))
+            over = m._shard.overflowed()
+            path = m._shard.last_path
+            # the weights change (a step of an optimizer elsewhere, load_state_dict): the hot copy follows the re-cut shard
+            m.embedding.embedding.weight.mul_(1.5)
+            want2 = None
+            m2 = build_model(meta, sd, dev)
+            m2.embedding.embedding.weight.mul_(1.5)
+            want2 = m2.arm_block(ids.to(dev), vals.clone().to(dev))
+            got2 = m.arm_block(ids.to(dev), vals.clone().to(dev))
+        q.put((rank, bool(torch.equal(got, want)), bool(torch.equal(got2, want2)), over, path,
+               int(m._shard.hot_table().shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup,micro", [(False, 1), (True, 1), (True, 3), (False, 4)])
+def test_hot_rows_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro):
+    """RowShardedTable(hot_rows=512) with the real kernels (armnet_shard_route_fixed_hot, the position gather on the side
+    stream, the fused block over [received rows | hot rows]) under a skewed id stream: bit-equal to the replicated table,
+    before and after a weight update"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29801 + 2 * int(dedup) + micro
+    procs = [ctx.Process(target=_worker_hot, args=(r, 2, port, dedup, micro, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ok2, over, path, nhot in res:
+        assert ok and ok2 and not over and path == "fixed" and nhot == 512, res
+
+
+def test_hot_rows_world1_without_a_process_group_and_through_the_module():
+    """one rank, no torch.distributed (bench.py --shard rows on one GPU): the owner gather writes into the front of the
+    consumer's buffer, the hot rows follow; both routings; int32 ids"""
+    for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from golden_util import load
+    from model_util import build_model
+    dev = "cuda:0"
+    meta, sd, _, _, _ = load("g3_criteo_mh4_a1.7_stress")
+    c = meta["ctor"]
+    g = torch.Generator().manual_seed(5)
+    ids = _zipf(c["nfeat"], (401, c["nfield"]), g).to(dev)
+    vals = torch.rand(401, c["nfield"], generator=g).to(dev)
+    m = build_model(meta, sd, dev)
+    with torch.no_grad():
+        want = m.arm_block(ids, vals.clone())
+        m.shard_embedding(hot_rows=300)
+        for dedup in (False, True):
+            for idt in (ids, ids.to(torch.int32)):
+                m._shard.dedup, m._shard.whole_shard, m._shard.slot_lookups = dedup, False, None
+                got = m.arm_block(idt, vals.clone())
+                assert torch.equal(got, want) and m._shard.last_path == "fixed" and not m._shard.overflowed()
