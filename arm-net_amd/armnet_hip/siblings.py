@@ -191,11 +191,14 @@ class _GcBlockFn(torch.autograd.Function):
         native.gc_fused_bwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table.detach(), qf, vflat, e_scale, e_shift, z, dy,
                             cA, cB, cC, d_table, d_values, d_qf, d_y)
         d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(ex, d_y, emb_w.detach(), e_mean, e_rstd)
-        native.bn_bwd_scatter(ids, vals, ex, d_y, eA, eB, eC, 0, d_table)     # emb_bn backward, * exp(x), * value, scatter-add
+        need = ctx.needs_input_grad            # frozen parameters (round-4 advisor finding): no pass / contraction for them
+        if need[0]:
+            native.bn_bwd_scatter(ids, vals, ex, d_y, eA, eB, eC, 0, d_table)     # emb_bn backward, * exp(x), * value, scatter-add
         g3 = d_qf.view(K, H, E)                                              # q_fold[k,o,x] = sum_y bilinear[k,x,y] Q[k,o,y]
-        d_Q = torch.einsum("kox,kxy->koy", g3, bilinear)
-        d_bil = torch.einsum("kox,koy->kxy", g3, Q)
-        return (d_table, d_bil, d_Q, d_values.reshape(values.shape), d_ew, d_eb, d_aw, d_ab, None, None, None, None, None)
+        d_bil = torch.einsum("kox,koy->kxy", g3, Q) if need[1] else None
+        d_Q = torch.einsum("kox,kxy->koy", g3, bilinear) if need[2] else None
+        return (d_table if need[0] else None, d_bil, d_Q, d_values.reshape(values.shape) if need[3] else None, d_ew, d_eb,
+                d_aw, d_ab, None, None, None, None, None)
 
 
 class _AfnBlockFn(torch.autograd.Function):
@@ -239,8 +242,10 @@ class _AfnBlockFn(torch.autograd.Function):
         native.afn_fused_bwd(B, F, E, O, flags, ids, vals, table.detach(), wc, l_scale, l_shift, z, dy, cA, cB, cC, d_weight,
                              d_bias, d_y)
         d_ew, d_eb, eA, eB, eC = native.bn_backward_coef(lg, d_y, emb_w.detach(), l_mean, l_rstd)
-        d_table = torch.zeros_like(table)
-        native.bn_bwd_scatter(ids, vals, lg, d_y, eA, eB, eC, 1, d_table)     # emb_bn backward, / x = * exp(-log x), * value, scatter-add
+        d_table = None
+        if ctx.needs_input_grad[0]:            # a frozen table: no dense zeros, no scatter pass (round-4 advisor finding)
+            d_table = torch.zeros_like(table)
+            native.bn_bwd_scatter(ids, vals, lg, d_y, eA, eB, eC, 1, d_table)     # emb_bn backward, / x = * exp(-log x), * value, scatter-add
         return d_table, d_weight, d_bias, d_ew, d_eb, d_aw, d_ab, None, None, None, None, None
 
 
@@ -335,13 +340,15 @@ class GC_ARMModel(SiblingBase):
 
     fused_training = True        # developer switch: False keeps the composed device ops for every shape
 
-    def _fused_training_ok(self, F):
-        """training mode (batch statistics in both BatchNorm1d layers, affine parameters present) on a shape the
-        matrix-core backward has a kernel for; everything else runs the composed device ops below"""
+    def _fused_training_ok(self, ids, v_run):
+        """training mode (batch statistics in both BatchNorm1d layers, affine parameters present) on device float32
+        tensors and a shape the matrix-core backward has a kernel for; everything else runs the composed ops below"""
         plain = all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
                     for bn in (self.emb_bn, self.arm_bn))
-        return (self.fused_training and self.training and plain
-                and native.gc_fused_bwd_supported(F, self.nemb, self.nhead * self.arm_hid))
+        w = self.embedding.embedding.weight
+        on_dev = ids.is_cuda and v_run.is_cuda and w.is_cuda and v_run.dtype == torch.float32 and w.dtype == torch.float32
+        return (self.fused_training and self.training and plain and on_dev
+                and native.gc_fused_bwd_supported(v_run.shape[1], self.nemb, self.nhead * self.arm_hid))
 
     def _arm_block_autograd(self, ids, v_run):
         """gc_arm.py:86-94 as differentiable device ops (train mode: batch statistics in both BatchNorm1d layers)"""
@@ -349,14 +356,15 @@ class GC_ARMModel(SiblingBase):
         B = v_run.shape[0]
         K, H, E = self.nhead, self.arm_hid, self.nemb
         at = self.attn_layers
-        if self._fused_training_ok(v_run.shape[1]):
+        if self._fused_training_ok(ids, v_run):
             cfg = (K, H, E, self.alpha, self.n_iter, self.kernel_flags, self.check_ids)
             w = self.embedding.embedding.weight
-            self.emb_bn.num_batches_tracked.add_(1)
+            out = _GcBlockFn.apply(w, at.bilinear, at.Q, at.values, self.emb_bn.weight, self.emb_bn.bias,
+                                   self.arm_bn.weight, self.arm_bn.bias, ids, v_run, cfg, _bn_state(self.emb_bn),
+                                   _bn_state(self.arm_bn))
+            self.emb_bn.num_batches_tracked.add_(1)      # only a forward that did not raise (a bad id) counts as a batch
             self.arm_bn.num_batches_tracked.add_(1)
-            return _GcBlockFn.apply(w, at.bilinear, at.Q, at.values, self.emb_bn.weight, self.emb_bn.bias,
-                                    self.arm_bn.weight, self.arm_bn.bias, ids, v_run, cfg, _bn_state(self.emb_bn),
-                                    _bn_state(self.arm_bn))
+            return out
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E]
         x_exp = self.emb_bn(torch.exp(x_emb))                                    # channel = field (gc_arm.py:89)
         qb = torch.einsum("kxy,koy->kox", at.bilinear, at.Q).reshape(K * H, E)   # parameter-only fold of the bilinear form
@@ -439,21 +447,23 @@ class AFNModel(SiblingBase):
 
     fused_training = True        # developer switch: False keeps the composed device ops for every shape
 
-    def _fused_training_ok(self, F):
+    def _fused_training_ok(self, ids, v_run):
         plain = all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
                     for bn in (self.emb_bn, self.afn_bn))
-        return (self.fused_training and self.training and plain
-                and native.afn_fused_bwd_supported(F, self.nemb, self.afn_hid))
+        w = self.embedding.embedding.weight
+        on_dev = ids.is_cuda and v_run.is_cuda and w.is_cuda and v_run.dtype == torch.float32 and w.dtype == torch.float32
+        return (self.fused_training and self.training and plain and on_dev
+                and native.afn_fused_bwd_supported(v_run.shape[1], self.nemb, self.afn_hid))
 
     def _afn_block_autograd(self, ids, v_run):
         """afn.py:61-69 as differentiable device ops; Dropout (afn.py:69) acts on the block's output"""
-        if self._fused_training_ok(v_run.shape[1]):
+        if self._fused_training_ok(ids, v_run):
             cfg = (self.afn_hid, self.nemb, self.kernel_flags, self.check_ids)
-            self.emb_bn.num_batches_tracked.add_(1)
-            self.afn_bn.num_batches_tracked.add_(1)
             afn = _AfnBlockFn.apply(self.embedding.embedding.weight, self.afn.weight, self.afn.bias, self.emb_bn.weight,
                                     self.emb_bn.bias, self.afn_bn.weight, self.afn_bn.bias, ids, v_run, cfg,
                                     _bn_state(self.emb_bn), _bn_state(self.afn_bn))
+            self.emb_bn.num_batches_tracked.add_(1)      # only a forward that did not raise (a bad id) counts as a batch
+            self.afn_bn.num_batches_tracked.add_(1)
             return self.dropout(afn)
         x_emb = self._lookup_train(ids, v_run)                                   # [B,F,E], positive after the clip
         x_log = self.emb_bn(torch.log(x_emb))                                    # channel = field

@@ -11,7 +11,8 @@ namespace armnet {
 // ---- sparse-map solver selection (host side fills this, kernels take it by value) ------------
 enum SolverMode : int {
     SOLVE_SOFTMAX = 0,   // alpha == 1: nn.Softmax(dim=-1)                    (armnet_1h.py:12)
-    SOLVE_BISECT = 1,    // the reference's n_iter-step bisection, literally   (entmax.py:29-68)
+    SOLVE_BISECT = 1,    // the reference's n_iter-step bisection, statement for statement (entmax.py:29-68); t^r by the
+                         // hardware exp2 / log2 pair (pow_clamped below), not libm powf: see ARMNET_F_FAITHFUL_BISECT's note
     SOLVE_NEWTON = 2,    // 1 < alpha < 2: Newton from the left on the same root
     SOLVE_MICHELOT = 3,  // alpha == 2: Newton == Michelot's finite algorithm
     SOLVE_NEWTON15 = 4   // alpha == 1.5: Newton with p = t*t (no transcendental)

@@ -38,8 +38,9 @@ _CACHE_MAGIC = b"ARMNETDS"
 _CACHE_VERSION = 1
 
 
-def _cache_header(fname, nfields, nlines, nsamples, nskipped):
-    st = os.stat(fname)
+def _cache_header(st, nfields, nlines, nsamples, nskipped):
+    """st: os.stat of the text file taken BEFORE it was parsed (a file rewritten during the parse must not get a header
+    that validates what was parsed from its previous content: round-4 advisor finding)"""
     return np.array([_CACHE_VERSION, nfields, nlines, nsamples, nskipped, st.st_size, st.st_mtime_ns], dtype=np.int64)
 
 
@@ -100,6 +101,7 @@ class LibsvmDataset(Dataset):
                 return
         lib = _lib()
         path = os.fsencode(fname)
+        st_before = os.stat(fname) if cache_path else None
         nlines = int(lib.armnet_libsvm_count_lines(path))
         if nlines < 0:
             raise FileNotFoundError(fname)
@@ -120,8 +122,17 @@ class LibsvmDataset(Dataset):
             print(f"{self.nskipped} line(s) of incorrect data format skipped !")
         print(f"# {self.nsamples} data samples loaded...")
         if cache_path:
-            _cache_write(cache_path, _cache_header(fname, int(nfields), nlines, self.nsamples, self.nskipped), feat_id,
-                         feat_value, y)
+            # rows at and past nsamples (skipped lines) are uninitialised host memory: zero them, so that the cache bytes
+            # are a function of the text file alone and nothing of this process leaks into a file
+            feat_id[n:].zero_()
+            feat_value[n:].zero_()
+            y[n:].zero_()
+            st_after = os.stat(fname)
+            if (st_after.st_size, st_after.st_mtime_ns) == (st_before.st_size, st_before.st_mtime_ns):
+                _cache_write(cache_path, _cache_header(st_before, int(nfields), nlines, self.nsamples, self.nskipped),
+                             feat_id, feat_value, y)
+            else:
+                print(f"# {fname} changed while it was parsed: binary cache not written")
 
     def __len__(self):
         return self.nsamples

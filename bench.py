@@ -80,6 +80,9 @@ def parse():
                     help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
     ap.add_argument("--config4-capacity-factor", type=float, default=1.06,
                     help="slot slack of the fixed-capacity exchange in the configs[3] measurement")
+    ap.add_argument("--hot-rows", type=int, default=0,
+                    help="row-sharded variant: rows [0, N) of the (frequency-ordered) id space are replicated on every rank "
+                         "and never routed (SURVEY §8e's hot-row lever; meaningful with --ids zipf)")
     ap.add_argument("--no-config4", action="store_true",
                     help="N > 1: skip the extra row-sharded measurement of BASELINE.json configs[3] (nfeat 100 M, nemb 64)")
     ap.add_argument("--no-config5", action="store_true",
@@ -120,7 +123,8 @@ def build_model(a, device, rank=0, world=1, regime=None):
         gdev = torch.Generator(device=device).manual_seed(2025 + rank)
         shard = (torch.rand(n_local, a.nemb, device=device, generator=gdev) * 2 - 1) * bound
         m._shard = RowShardedTable(shard, a.nfeat, None, protocol=a.protocol,
-                                   dedup={"auto": "auto", "on": True, "off": False}[a.dedup])
+                                   dedup={"auto": "auto", "on": True, "off": False}[a.dedup],
+                                   hot_rows=int(getattr(a, "hot_rows", 0)))
         m._shard.micro_batches = a.micro_batches
         m._shard.whole_shard = "auto" if getattr(a, "whole_shard", "auto") == "auto" else False
         m.nfeat = a.nfeat
@@ -610,7 +614,7 @@ def main():
         def run_sharded():
             try:
                 torch.cuda.set_device(local)
-                model.shard_embedding()
+                model.shard_embedding(hot_rows=a.hot_rows)
                 model._shard.micro_batches = a.micro_batches
                 model._shard.protocol = a.protocol
                 model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
@@ -938,6 +942,21 @@ def main():
                         f"collective; median of 3 windows of {a.steps} steps, MAX over ranks"})
         if a.shard == "rows":
             line["row_sharded_overflow"] = sharded_overflow
+            line["row_sharded_path"] = getattr(model._shard, "last_path", None)
+            # what the links would carry at 8 ranks for THIS id stream, with and without the hot rows replicated: the slots
+            # of the fixed-capacity exchange are sized by the routed (cold) lookups, so the cut is the cold fraction
+            from armnet_hip.sharded import fixed_ingress_bytes
+            n_lk = a.batch * a.nfield
+            hot_n = int(a.hot_rows) or 65536
+            cold = int((ids_cpu >= hot_n).sum())
+            dd = {"auto": "auto", "on": True, "off": False}[a.dedup]
+            w_o, w_h = (fixed_ingress_bytes(n, 8, a.nfeat, a.nemb, dd) for n in (n_lk, max(cold, 1)))
+            line["hot_rows"] = {"rows": int(a.hot_rows), "priced_for_rows": hot_n, "cold_fraction": cold / n_lk,
+                                "replicated_bytes_per_rank": hot_n * a.nemb * 4,
+                                "ingress_bytes_per_rank_per_step_at_8_ranks": {"without": w_o, "with": w_h, "cut": w_o / w_h},
+                                "note": f"ids {a.ids}: rows [0, {hot_n}) of the id space (frequency-ordered for skewed click logs) "
+                                        "replicated on every rank; such ids take no slot and cross no link "
+                                        "(armnet_shard_route_fixed_hot); slots sized by the cold lookups of the first step"}
         if world == 1 and not a.no_cpu_baseline and a.shard == "replicate":
             a_head = argparse.Namespace(**vars(a))
             line["cpu_baseline"] = cpu_baseline(a_head, model, ids_cpu, vals_cpu)

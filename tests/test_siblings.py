@@ -167,7 +167,7 @@ def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alph
                 bn.bias.uniform_(-0.3, 0.3)
         m.fused_training = fused
         zero_names = _analytically_zero(m)
-        assert m._fused_training_ok(F) == fused
+        assert m._fused_training_ok(ids, vals) == fused
         v = vals.clone()
         logits = m({"id": ids, "value": v})
         torch.nn.BCEWithLogitsLoss()(logits, y).backward()
@@ -218,7 +218,7 @@ def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
             m.afn.bias.uniform_(-0.2, 0.2)
         m.fused_training = fused
         zero_names = _analytically_zero(m)
-        assert m._fused_training_ok(F) == fused
+        assert m._fused_training_ok(ids, vals) == fused
         v = vals.clone()
         logits = m({"id": ids, "value": v})
         torch.nn.BCEWithLogitsLoss()(logits, y).backward()
@@ -311,6 +311,43 @@ def test_sibling_backward_without_batchnorm_coefficients_is_the_identity_coeffic
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["gc", "afn"])
+def test_sibling_fused_step_with_frozen_parameters(kind):
+    """round-4 advisor finding: a frozen embedding table / frozen attention parameters get no gradient (and no dense
+    zeros + scatter pass is spent on them); the other gradients equal the all-trainable step's; a bad id raises before the
+    BatchNorm layers count the batch"""
+    from armnet_hip.siblings import AFNModel, GC_ARMModel
+    F, E, nfeat, B = 13, 8, 211, 96
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = torch.rand(B, F, generator=g).to(DEV)
+    y = (torch.rand(B, generator=g) > 0.5).float().to(DEV)
+    grads = []
+    for freeze in (False, True):
+        torch.manual_seed(9)
+        m = (GC_ARMModel(F, nfeat, E, 2, 1.7, 8, 1, 16, 0.0, False, 1, 16) if kind == "gc"
+             else AFNModel(F, nfeat, E, 24, 1, 16, 0.0, False, 1, 16)).to(DEV).train()
+        frozen = [m.embedding.embedding.weight] + ([m.attn_layers.Q] if kind == "gc" else [])
+        if freeze:
+            for p in frozen:
+                p.requires_grad_(False)
+        assert m._fused_training_ok(ids, vals)
+        torch.nn.BCEWithLogitsLoss()(m({"id": ids, "value": vals.clone()}), y).backward()
+        grads.append({k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()})
+        if freeze:
+            assert all(p.grad is None for p in frozen)
+            tracked = int(m.emb_bn.num_batches_tracked)
+            bad = ids.clone()
+            bad[3, 2] = nfeat
+            with pytest.raises(IndexError):
+                m({"id": bad, "value": vals.clone()})
+            assert int(m.emb_bn.num_batches_tracked) == tracked
+    for k, gfree in grads[1].items():
+        if gfree is not None:
+            assert torch.equal(gfree, grads[0][k]) or float((gfree - grads[0][k]).abs().max()) <= 1e-6 * float(grads[0][k].abs().max() + 1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gc", "afn"])
 def test_sibling_graphed_train_step_equals_eager_steps(kind):
     """the fused sibling training step inside armnet_hip.modules.GraphedTrainStep (one hipGraph: no host sync, no
     allocation inside the autograd.Functions that a capture cannot replay) against the same SGD steps run eagerly"""
@@ -326,7 +363,7 @@ def test_sibling_graphed_train_step_equals_eager_steps(kind):
         torch.manual_seed(3)
         m = (GC_ARMModel(F, nfeat, E, 2, 1.7, 24, 1, 32, 0.0, False, 1, 16) if kind == "gc"
              else AFNModel(F, nfeat, E, 40, 1, 32, 0.0, False, 1, 16)).to(DEV).train()
-        assert m._fused_training_ok(F)
+        assert m._fused_training_ok(batches[0][0], batches[0][1])
         opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
         losses = []
         if graphed:
