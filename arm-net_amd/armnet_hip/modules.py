@@ -184,6 +184,57 @@ class _LinearSplitKFn(torch.autograd.Function):
         return dx, dw, (dy.sum(0) if ctx.needs_input_grad[2] else None)
 
 
+def _linear_mfma_ok(x, weight):
+    """shapes the bf16x3 matrix-core Linear (armnet_linear_bf16x3_f32) takes for BOTH the forward and the input gradient:
+    device float32, widths in whole 16-float k-steps (every head width BASELINE.json builds: 512 / 2048 / 704 -> 256)"""
+    N, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] >= 2048 and K % 16 == 0 and N % 16 == 0 and N >= 32)
+
+
+def _linear_mfma(x, W, bias):
+    """bias + x @ W.T for W [N, K] through armnet_linear_bf16x3_f32, in slices of <= 256 outputs; the weights are packed
+    (three bf16 planes in the kernel's operand order) per call: they change with every optimizer step"""
+    B, K = x.shape
+    N = W.shape[0]
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    for n0 in range(0, N, 256):
+        n1 = min(N, n0 + 256)
+        blob = torch.zeros(native.mlp_packed_bytes(K, n1 - n0, 1), device=x.device, dtype=torch.uint8)
+        native.mlp_pack_layer(K, n1 - n0, 1, 0, W[n0:n1].contiguous(), None if bias is None else bias[n0:n1].contiguous(),
+                              None, blob)
+        native.linear_bf16x3(x, blob, out[:, n0:], K, n1 - n0)
+    return out
+
+
+class _LinearMfmaFn(torch.autograd.Function):
+    """nn.Linear of the TRAINING head on the bf16 matrix cores (round 5): forward x W^T + b and the input gradient dY W as
+    armnet_linear_bf16x3_f32 launches (three-way bf16 split of both operands, six cross products, fp32 accumulate: the
+    error class of an fp32 GEMM at 6/16 of its matrix-pipe time); the weight gradient dY^T X stays the split-K batched
+    GEMM of _LinearSplitKFn (its contraction runs over the samples: both operands would need a run-time split AND a
+    transpose — not built)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return _linear_mfma(x, weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        B = x.shape[0]
+        dx = _linear_mfma(dy, weight.detach().t(), None) if ctx.needs_input_grad[0] else None
+        S = 1
+        while S < 64 and B % (2 * S) == 0 and B // (2 * S) >= 1024:
+            S *= 2
+        if S > 1:
+            dw = torch.bmm(dy.reshape(S, B // S, -1).transpose(1, 2), x.reshape(S, B // S, -1)).sum(0)
+        else:
+            dw = dy.t() @ x
+        return dx, dw, (dy.sum(0) if ctx.needs_input_grad[2] else None)
+
+
 class HipBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters, buffers and state_dict keys) whose TRAINING forward/backward on the GPU
     run as the HBM-bound HIP passes of bn_kernels.hip; eval mode and anything unusual (no affine, no running
@@ -551,6 +602,7 @@ class _MLP(nn.Module):
         self._folded = None
         self.fold_eval = True
         self.hip_head = True           # eval-mode inference through armnet_mlp_head_f32 where it has a kernel
+        self.mfma_train = True         # training-mode Linear forward / dX through armnet_linear_bf16x3_f32 where it fits
         self._dims = (ninput, nlayers, nhid, noutput)
         self._pack_key = {}
         self._packed = {}              # ens flag -> [(K0, n_hidden, has_final, blob)] one entry per launch
@@ -720,7 +772,11 @@ class _MLP(nn.Module):
             while i < len(mods):
                 m = mods[i]
                 if isinstance(m, nn.Linear) and m.bias is not None and x.dim() == 2 and x.shape[0] >= 2048:
-                    h = _LinearSplitKFn.apply(x.contiguous(), m.weight, m.bias)
+                    xc = x.contiguous()
+                    if self.mfma_train and _linear_mfma_ok(xc, m.weight):
+                        h = _LinearMfmaFn.apply(xc, m.weight, m.bias)      # bf16x3 matrix cores: forward and dX
+                    else:
+                        h = _LinearSplitKFn.apply(xc, m.weight, m.bias)
                 else:
                     h = m(x)
                 if (isinstance(m, nn.Linear) and i + 2 < len(mods) and isinstance(mods[i + 1], HipBatchNorm1d)

@@ -37,6 +37,7 @@ EXPORTS = (
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
     "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
+    "armnet_linear_bf16x3_f32",
 )
 
 _lib = None
@@ -506,6 +507,20 @@ def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
         check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(has_final),
                                          _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
                                          _stream()))
+
+
+def linear_bf16x3(x, packed, out, K, N):
+    """out[:, :N] = bias + x[:, :K] @ W.T on the head's bf16x3 matrix-core path (armnet_linear_bf16x3_f32); `packed` from
+    mlp_pack_layer(K, N, 1, 0, W, bias, None, packed).  x / out: float32, unit inner stride, row strides >= the padded widths"""
+    for t, n in ((x, "x"), (out, "out")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise ArmnetNativeError(f"{n}: expected a float32 2-d tensor with unit inner stride on the HIP device")
+    B = x.shape[0]
+    ldx = x.stride(0) if B > 1 else max(x.stride(0), x.shape[1])
+    ldo = out.stride(0) if B > 1 else max(out.stride(0), out.shape[1])
+    with _on(x, packed, out):
+        check(load().armnet_linear_bf16x3_f32(ctypes.c_int64(B), int(K), int(N), _ptr(x), ctypes.c_int64(ldx), _ptr(packed),
+                                              _ptr(out), ctypes.c_int64(ldo), _stream()))
 
 
 def gc_fused_fwd(B, F, E, O, alpha, n_iter, flags, ids, vals, table, q_fold, values, emb_scale, emb_shift, bn_scale,

@@ -153,6 +153,8 @@ struct MlpArgs {
     const uint8_t* packed;
     float* out;
     int dbg;      // developer ablation switches (ARMNET_DEV_FLAGS builds only; 0 in product builds)
+    int linear;   // 1: a plain Linear — hidden activations are written WITHOUT the ReLU (armnet_linear_bf16x3_f32: the
+                  // training head's GEMMs, where BatchNorm needs the batch's pre-activation values)
 };
 
 // 8 fp32 -> three packed bf16x8 planes; h + m + l == x exactly (truncating 8-bit slices of the significand)
@@ -453,7 +455,10 @@ __global__ void __launch_bounds__(64 * kWaves, kWaves >= 8 ? 2 : 1) mlp_head_ker
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r] + tabs[(hf * NT + t) * 16 + r], 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][r] + tabs[(hf * NT + t) * 16 + r];
+            acc[t][r] = a.linear ? v : fmaxf(v, 0.f);
+        }
 
     float part = 0.f;
     const float* wl = tabs + 2 * NT * 32;
@@ -627,6 +632,25 @@ int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final
     if (const char* e = getenv("ARMNET_MLP_DBG")) a.dbg = atoi(e);
 #endif
     switch (mlp_nt_for(nhid)) {
+        case 1: return launch_mlp<1>(a, (hipStream_t)stream);
+        case 2: return launch_mlp<2>(a, (hipStream_t)stream);
+        case 4: return launch_mlp<4>(a, (hipStream_t)stream);
+        case 8: return launch_mlp<8>(a, (hipStream_t)stream);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+
+// A plain Linear on the same kernel (round 5): out[b, n] = bias[n] + sum_k x[b, k] W[n, k], N <= 256 outputs, no
+// BatchNorm fold, no ReLU.  `packed` = armnet_mlp_pack_layer_f32(K, N, 1, slot 0, W [N, K], K, bias | NULL, no BatchNorm).
+int armnet_linear_bf16x3_f32(int64_t B, int K, int N, const float* x, int64_t ldx, const void* packed, float* out,
+                             int64_t ldo, void* stream) {
+    if (B < 0 || !armnet_mlp_head_supported(K, N, 1) || ldx < (int64_t)((K + 15) / 16) * 16 || ldo < N) return ARMNET_ERR_BAD_ARG;
+    if (B == 0) return ARMNET_OK;
+    if (!x || !packed || !out) return ARMNET_ERR_BAD_ARG;
+    MlpArgs a{};
+    a.B = B; a.K0 = K; a.n_hidden = 1; a.has_final = 0; a.N = N; a.ldx = ldx; a.ldo = ldo;
+    a.x = x; a.packed = static_cast<const uint8_t*>(packed); a.out = out; a.linear = 1;
+    switch (mlp_nt_for(N)) {
         case 1: return launch_mlp<1>(a, (hipStream_t)stream);
         case 2: return launch_mlp<2>(a, (hipStream_t)stream);
         case 4: return launch_mlp<4>(a, (hipStream_t)stream);

@@ -35,7 +35,7 @@ extern "C" {
  *   4  round 4: armnet_shard_route_fixed(_perm, _epoch), armnet_shard_gather_perm_f32, GC-ARM / AFN fused backward,
  *               armnet_gather_map_stats_f32, armnet_bn_bwd_scatter_f32
  *   5  round 5: hot-row replication of the row-sharded lookup (armnet_shard_route_fixed_hot, _perm_hot,
- *               armnet_shard_gather_perm_hot_f32) */
+ *               armnet_shard_gather_perm_hot_f32); armnet_linear_bf16x3_f32 (the training head's GEMMs) */
 #define ARMNET_ABI_VERSION 5
 
 typedef enum armnet_status {
@@ -455,6 +455,18 @@ int armnet_gc_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_i
  */
 int armnet_linear_small_f32(int64_t B, int K, int N, const float* x, int64_t ldx, const float* W, const float* bias,
                             float scale, float* out, int64_t ldo, int accumulate, void* stream);
+
+/*
+ * A plain Linear on the head's matrix-core path (round 5): out[b, n] = bias[n] + sum_k x[b, k] W[n, k] for N <= 256 outputs,
+ * bf16x3-split operands, six cross products, fp32 accumulate — the GEMMs of the TRAINING head (models/layers.py:68-88 under
+ * train.py:108-114: nn.Linear forward, and its input gradient dX = dY W as a Linear with the transposed weight), where
+ * BatchNorm1d needs the batch's pre-activation values, so nothing is folded and no ReLU is applied.
+ * packed = armnet_mlp_pack_layer_f32(K, N, 1, 0, W [N, K], K, bias | NULL, NULL, NULL, NULL, NULL, 0, packed) of
+ * armnet_mlp_packed_bytes(K, N, 1) bytes — a per-step precompute here, the weights change with every optimizer step.
+ * x [B, K] row stride ldx >= 16 * ceil(K / 16) (columns past K readable and finite), out [B, N] row stride ldo >= N.
+ */
+int armnet_linear_bf16x3_f32(int64_t B, int K, int N, const float* x, int64_t ldx, const void* packed, float* out,
+                             int64_t ldo, void* stream);
 
 int armnet_mlp_head_supported(int K0, int nhid, int n_hidden);
 int64_t armnet_mlp_packed_bytes(int K0, int nhid, int n_hidden);

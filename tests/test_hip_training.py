@@ -272,3 +272,61 @@ def test_generic_backward_handles_more_than_256_neurons(F, E, O):
     native.fused_bwd(B, F, E, O, 1.0, 50, 0, ids, vals, table.detach(), qf.detach(), values.detach(), z, dz, dt, dv, dq)
     for name, a, b in (("d_table", dt, table.grad), ("d_values", dv, values.grad), ("d_qfold", dq, qf.grad)):
         assert float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) <= 2e-5, name
+
+
+@pytest.mark.parametrize("K,N,B", [(512, 256, 4096), (256, 256, 2048), (2048, 256, 2304), (704, 512, 2048), (64, 32, 3000)])
+def test_matrix_core_linear_of_the_training_head_matches_nn_linear(K, N, B):
+    """armnet_linear_bf16x3_f32 (round 5): forward x W^T + b and the input gradient dY W of the training head's nn.Linear on
+    the bf16 matrix cores (three-way split of both operands, six products) against float64 — held to the error of the
+    fp32 hipBLASLt GEMM on the same inputs (x2), outputs wider than 256 as slices; the weight gradient is the split-K GEMM"""
+    from armnet_hip.modules import _LinearMfmaFn, _linear_mfma_ok
+    g = torch.Generator().manual_seed(K + N)
+    x = (torch.randn(B, K, generator=g) * 1.5).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.mul_(3.0)
+    dy = torch.randn(B, N, generator=g).to(DEV)
+    assert _linear_mfma_ok(x, lin.weight)
+    y = _LinearMfmaFn.apply(x, lin.weight, lin.bias)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    y32 = lin(x)
+    y32.backward(dy)
+    ref32 = (y32.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x64, w64, b64, dy64 = (t.detach().double() for t in (x, lin.weight, lin.bias, dy))
+    ref64 = (x64 @ w64.t() + b64, dy64 @ w64, dy64.t() @ x64, dy64.sum(0))
+    for name, a, b, c in zip(("y", "dx", "dw", "db"), got, ref32, ref64):
+        scale = float(c.abs().max())
+        e_got, e_32 = float((a.double() - c).abs().max()) / scale, float((b.double() - c).abs().max()) / scale
+        assert e_got <= max(2.0 * e_32, 2e-7), (name, e_got, e_32)
+
+
+def test_training_step_with_the_matrix_core_head_equals_the_hipblaslt_head():
+    """a whole ARM-Net training step at B = 4096 (the reference's batch size, train.py:21) with the head's Linear forward /
+    dX on armnet_linear_bf16x3_f32 against the same step with hipBLASLt GEMMs: logits and every gradient"""
+    from models.armnet_1h import ARMNetModel
+    g = torch.Generator().manual_seed(2)
+    F, E, H, nfeat, B = 39, 16, 32, 5000, 4096
+    ids = torch.randint(0, nfeat, (B, F), generator=g).to(DEV)
+    vals = torch.rand(B, F, generator=g).to(DEV)
+    y = (torch.rand(B, generator=g) > 0.5).float().to(DEV)
+    res = []
+    for mfma in (False, True):
+        torch.manual_seed(11)
+        m = ARMNetModel(F, nfeat, E, 1.7, H, E, 2, 256, 0.0, False, 2, 256).to(DEV).train()
+        with torch.no_grad():
+            m.attn_layer.query.mul_(4.0)
+            m.embedding.embedding.weight.normal_(0, 0.5)
+        m.mlp.mfma_train = mfma
+        logits = m({"id": ids, "value": vals.clone()})
+        torch.nn.BCEWithLogitsLoss()(logits, y).backward()
+        res.append((logits.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * max(1.0, float(res[0][0].abs().max()))
+    gmax = max(float(v.abs().max()) for v in res[0][1].values())
+    for k, gref in res[0][1].items():
+        if float(gref.abs().max()) < 1e-6 * gmax:
+            continue
+        err = float((res[1][1][k] - gref).abs().max()) / float(gref.abs().max())
+        assert err <= 5e-5, (k, err)

@@ -343,7 +343,7 @@ def test_sibling_fused_step_with_frozen_parameters(kind):
             assert int(m.emb_bn.num_batches_tracked) == tracked
     for k, gfree in grads[1].items():
         if gfree is not None:
-            assert torch.equal(gfree, grads[0][k]) or float((gfree - grads[0][k]).abs().max()) <= 1e-6 * float(grads[0][k].abs().max() + 1e-12), k
+            assert torch.equal(gfree, grads[0][k]) or float((gfree - grads[0][k]).abs().max()) <= 2e-5 * float(grads[0][k].abs().max() + 1e-12), k   # (float-atomic order)
 
 
 @pytest.mark.gpu

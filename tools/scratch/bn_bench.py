@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BatchNorm pass timing (developer tool, GPU box): HipBatchNorm1d training forward / backward vs torch's."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd")):
     sys.path.insert(0, p)
 import torch

@@ -2,7 +2,7 @@
 """What the in-place clamp write-back costs (developer tool, GPU box): the fused kernel on a batch whose values were
 already clamped by an earlier call (bench.py's steady state) against a fresh batch every call."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd")):
     sys.path.insert(0, p)
 import torch

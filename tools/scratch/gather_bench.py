@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """armnet_gather_scale_f32 / armnet_scatter_add_f32 timing (developer tool, GPU box)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd")):
     sys.path.insert(0, p)
 import torch

@@ -1,7 +1,7 @@
 """Host time per arm_block call (ctypes + guards) and a cProfile of it."""
 import sys, time
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "arm-net_amd")); sys.path.insert(0, ROOT)
 import torch
 from models.armnet_1h import ARMNetModel

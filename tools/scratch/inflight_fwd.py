@@ -1,6 +1,6 @@
 """Whole forward with 1 / 2 / 3 batches in flight on alternating streams (rotating batches), samples/s."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
 import torch
 import bench

@@ -13,7 +13,7 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 args = sys.argv[1] if len(sys.argv) > 1 else "16,10,2,SOLVE_MICHELOT,0,3,MODEL_ARM"
 with tempfile.TemporaryDirectory() as d:
     src = os.path.join(d, "k.hip")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (dev build of the library, GPU box): per-phase s_memtime sums of mlp_head_kernel's layer-1 stages."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "arm-net_amd")):
     sys.path.insert(0, p)
 import torch

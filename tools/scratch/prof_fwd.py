@@ -1,7 +1,7 @@
 """torch.profiler view of a few whole forwards (kernels, copies, host ops)."""
 import sys
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "arm-net_amd")); sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import profile, ProfilerActivity

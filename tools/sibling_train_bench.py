@@ -22,6 +22,8 @@ def main():
             torch.manual_seed(0)
             m = build().cuda().train()
             m.check_ids = False
+            if os.environ.get("ARMNET_HEAD_GEMM", "mfma") == "hipblaslt":   # A/B: the head's Linear forward / dX on hipBLASLt fp32
+                m.mlp.mfma_train = False
             opt = torch.optim.Adam(m.parameters(), lr=1e-3)
             ids = torch.randint(0, nfeat, (B, F)).cuda()
             vals = torch.rand(B, F).cuda()

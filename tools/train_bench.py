@@ -14,6 +14,9 @@ def main():
     torch.manual_seed(0)
     m = ARMNetModel(F, nfeat, E, alpha, H, E, 2, 256, 0.0, False, 2, 256).cuda().train()
     m.check_ids = False
+    if os.environ.get("ARMNET_HEAD_GEMM", "mfma") == "hipblaslt":   # A/B: the head's Linear forward / dX on hipBLASLt fp32 (rounds 1-4)
+        m.mlp.mfma_train = False
+    print("head GEMMs:", "armnet_linear_bf16x3_f32 (forward, dX) + split-K dW" if m.mlp.mfma_train else "hipBLASLt fp32")
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     ids = torch.randint(0, nfeat, (B, F)).cuda(); vals = torch.rand(B, F).cuda(); y = (torch.rand(B) > 0.5).float().cuda()
     lossf = torch.nn.BCEWithLogitsLoss()
