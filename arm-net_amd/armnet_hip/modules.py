@@ -602,7 +602,12 @@ class _MLP(nn.Module):
         self._folded = None
         self.fold_eval = True
         self.hip_head = True           # eval-mode inference through armnet_mlp_head_f32 where it has a kernel
-        self.mfma_train = True         # training-mode Linear forward / dX through armnet_linear_bf16x3_f32 where it fits
+        self.mfma_train = False        # training-mode Linear forward / dX through armnet_linear_bf16x3_f32 (round 5).  OFF:
+                                       # measured 2.13 ms against 2.09 ms per step at B = 65 536 and 0.94 against 0.75 ms
+                                       # graphed at B = 4 096 (profiles/r05_train_step_times.txt) — one layer per launch
+                                       # (training BatchNorm needs the batch's pre-activations, so nothing chains in
+                                       # registers) re-streams and re-packs the weights for 85 us where hipBLASLt's fp32
+                                       # GEMM takes 60-110, and dX of a 512-wide input is two slices
         self._dims = (ninput, nlayers, nhid, noutput)
         self._pack_key = {}
         self._packed = {}              # ens flag -> [(K0, n_hidden, has_final, blob)] one entry per launch

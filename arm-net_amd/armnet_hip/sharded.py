@@ -187,11 +187,12 @@ def slot_capacity(n, R, nfeat, dedup, capacity_factor=1.25):
     return max(cap, 1)
 
 
-def fixed_ingress_bytes(n_routed, R, nfeat, E, dedup="auto", capacity_factor=1.25):
+def fixed_ingress_bytes(n_routed, R, nfeat, E, dedup="auto", capacity_factor=1.25, n_distinct=None):
     """bytes ONE rank receives from its R - 1 peers per step of the fixed-capacity protocol when n_routed lookups are
-    routed (all of them, or the cold ones with hot rows replicated): the rows it asked for + the request lists it answers"""
+    routed (all of them, or the cold ones with hot rows replicated): the rows it asked for + the request lists it answers.
+    n_distinct: distinct ids among them — what a de-duplicating route sizes its slots by (RowShardedTable.slot_distinct)"""
     dd = (8 * n_routed >= nfeat) if dedup == "auto" else bool(dedup)
-    cap = slot_capacity(n_routed, R, nfeat, dd, capacity_factor)
+    cap = slot_capacity(n_distinct if (dd and n_distinct is not None) else n_routed, R, nfeat, dd, capacity_factor)
     return cap * (E * 4 + 4) * (R - 1)
 
 
@@ -221,6 +222,9 @@ class RowShardedTable:
         self.gather_with_perm = True   # de-dup, no side stream: position gather inside the owner-side gather's launch
         self.slot_lookups = None  # lookups per step the slots of the fixed protocol are sized for; None: agreed over the
                                   # ranks (MAX) by the first lookup — see _agreed_lookups
+        self.slot_distinct = None # de-duplicating route: DISTINCT routed ids per step the slots are sized for (round 5: a
+                                  # skewed stream asks for far fewer rows than it has lookups); measured on the first
+                                  # lookup, agreed like slot_lookups, re-measured after an overflow
         self.table_local = table_local
         self.nfeat = int(nfeat)
         self.group = group
@@ -317,6 +321,21 @@ class RowShardedTable:
             self._cold_frac = (cold / n) if n else 1.0
         return max(1, int(self._cold_frac * n + 0.999999))
 
+    def _agreed_distinct(self, flat, n_slot):
+        """de-duplicating route: distinct routed (cold) ids per step, MAX over the ranks, measured on the first lookup after
+        the step size was (re-)agreed — one torch.unique + host read + tiny all-reduce, where `_agreed_lookups` synchronises
+        anyway.  Uniform ids: ~ the lookups or the table, whichever is smaller; a skewed click log: a fraction of them."""
+        if self.slot_distinct is None:
+            cold = flat[flat >= self.hot_rows] if self.hot_rows else flat
+            d = max(int(torch.unique(cold).numel()) if cold.numel() else 0, 1)
+            if dist.is_initialized() and self.world > 1:
+                dev = self._table_local.device
+                t = torch.tensor([d], dtype=torch.int64, device="cpu" if self._via_host or not dev.type == "cuda" else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                d = int(t.item())
+            self.slot_distinct = d
+        return min(int(self.slot_distinct), int(n_slot))
+
     def capacity(self, n, dedup):
         """slot size of the fixed protocol for n lookups: the mean n/R plus the slack factor and a few standard
         deviations for small batches; with de-duplication never more than the owner's shard"""
@@ -351,6 +370,8 @@ class RowShardedTable:
             h = f.cpu()
         if self._overflow is not None:
             self._overflow.zero_()
+        if bool(h[0].item()):
+            self.slot_distinct = None                  # a slot overflowed somewhere: every rank re-measures at its next lookup
         if getattr(self, "_slot_auto", False) and self.slot_lookups is not None and int(h[2].item()) > self.slot_lookups:
             self.slot_lookups = int(h[2].item())   # a larger step than the agreed one was seen somewhere: same value on every rank
         return bool(h[0].item()), bool(h[1].item())
@@ -374,9 +395,12 @@ class RowShardedTable:
         # slot size, de-duplication and the exchange path are functions of the AGREED step size, not of this rank's
         # batch: every rank derives the same collectives from it whatever its own batch looks like
         N = self.hot_rows
+        first = self.slot_lookups is None
         n_slot = self._agreed_lookups(self._cold_lookups(flat) if N else n)
         dedup = (8 * n_slot >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
-        cap = self.capacity(n_slot, dedup)
+        if first:
+            self.slot_distinct = None
+        cap = self.capacity(self._agreed_distinct(flat, n_slot) if dedup else n_slot, dedup)
         L = (self.nfeat + R - 1) // R
         if self.whole_shard is True or (self.whole_shard == "auto" and dedup and cap >= L):
             self.last_path = "whole_shards"

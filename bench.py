@@ -603,7 +603,7 @@ def main():
             else:
                 n_slot = sh.slot_lookups or n_lk
                 dd = (8 * n_slot >= a.nfeat) if sh.dedup == "auto" else bool(sh.dedup)
-                cap = sh.capacity(n_slot, dd)
+                cap = sh.capacity(min(sh.slot_distinct or n_slot, n_slot) if dd else n_slot, dd)
                 per_peer = cap * (E4 + 4)                    # the rows it asked for + the request list it answers
                 mode["slot_rows"] = cap
             mode["ingress_bytes_per_rank_per_step"] = per_peer * (R - 1)
@@ -950,9 +950,11 @@ def main():
             hot_n = int(a.hot_rows) or 65536
             cold = int((ids_cpu >= hot_n).sum())
             dd = {"auto": "auto", "on": True, "off": False}[a.dedup]
-            w_o, w_h = (fixed_ingress_bytes(n, 8, a.nfeat, a.nemb, dd) for n in (n_lk, max(cold, 1)))
+            u_all = int(torch.unique(ids_cpu).numel())
+            u_cold = int(torch.unique(ids_cpu[ids_cpu >= hot_n]).numel())
+            w_o, w_h = (fixed_ingress_bytes(n, 8, a.nfeat, a.nemb, dd, n_distinct=u) for n, u in ((n_lk, u_all), (max(cold, 1), max(u_cold, 1))))
             line["hot_rows"] = {"rows": int(a.hot_rows), "priced_for_rows": hot_n, "cold_fraction": cold / n_lk,
-                                "replicated_bytes_per_rank": hot_n * a.nemb * 4,
+                                "replicated_bytes_per_rank": hot_n * a.nemb * 4, "distinct_ids": u_all, "distinct_cold_ids": u_cold,
                                 "ingress_bytes_per_rank_per_step_at_8_ranks": {"without": w_o, "with": w_h, "cut": w_o / w_h},
                                 "note": f"ids {a.ids}: rows [0, {hot_n}) of the id space (frequency-ordered for skewed click logs) "
                                         "replicated on every rank; such ids take no slot and cross no link "

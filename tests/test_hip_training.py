@@ -305,7 +305,8 @@ def test_matrix_core_linear_of_the_training_head_matches_nn_linear(K, N, B):
 
 def test_training_step_with_the_matrix_core_head_equals_the_hipblaslt_head():
     """a whole ARM-Net training step at B = 4096 (the reference's batch size, train.py:21) with the head's Linear forward /
-    dX on armnet_linear_bf16x3_f32 against the same step with hipBLASLt GEMMs: logits and every gradient"""
+    dX on armnet_linear_bf16x3_f32 (`mlp.mfma_train = True`: built in round 5, measured, left off by default) against the
+    same step with hipBLASLt GEMMs: logits and every gradient"""
     from models.armnet_1h import ARMNetModel
     g = torch.Generator().manual_seed(2)
     F, E, H, nfeat, B = 39, 16, 32, 5000, 4096

@@ -401,7 +401,7 @@ def _hot_worker(rank, world, port, q, dedup, hot_rows):
 def test_hot_rows_are_served_locally_and_shrink_the_exchange_gloo(world, dedup):
     """RowShardedTable(hot_rows=N): rows[perm] still reproduces table[ids] bit for bit (ids on both sides of the hot
     boundary, duplicates, a colder second step, a re-cut shard), the hot ids take no slot, and the slots — what the row
-    exchange carries — shrink with the cold fraction of the skewed stream (>= 3x here)"""
+    exchange carries — shrink with the cold fraction of the skewed stream"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 38500 + os.getpid() % 2000 + 3 * world + dedup
@@ -418,7 +418,9 @@ def test_hot_rows_are_served_locally_and_shrink_the_exchange_gloo(world, dedup):
             assert ok and ok2 and ok3 and not over and path in ("fixed", "exact"), (rank, name, out)
     assert len({out["hot"][2] for _, out in res}) == 1                  # the same slot size on every rank
     cold_rows, hot_rows_ = res[0][1]["cold"][2], res[0][1]["hot"][2]
-    assert hot_rows_ * 3 <= cold_rows, (cold_rows, hot_rows_)
+    # without de-duplication the slots shrink with the cold fraction of the lookups (>= 3x here); a de-duplicating route
+    # already sizes its slots by DISTINCT ids (round 5), of which the hot head is a smaller share (>= 2x)
+    assert hot_rows_ * (2 if dedup else 3) <= cold_rows, (cold_rows, hot_rows_)
 
 
 def test_hot_rows_on_one_rank_without_a_process_group():

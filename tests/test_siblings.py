@@ -341,9 +341,11 @@ def test_sibling_fused_step_with_frozen_parameters(kind):
             with pytest.raises(IndexError):
                 m({"id": bad, "value": vals.clone()})
             assert int(m.emb_bn.num_batches_tracked) == tracked
+    gmax = max(float(g_.abs().max()) for g_ in grads[0].values() if g_ is not None)
     for k, gfree in grads[1].items():
-        if gfree is not None:
-            assert torch.equal(gfree, grads[0][k]) or float((gfree - grads[0][k]).abs().max()) <= 2e-5 * float(grads[0][k].abs().max() + 1e-12), k   # (float-atomic order)
+        if gfree is not None and float(grads[0][k].abs().max()) >= 1e-5 * gmax:     # (analytically zero ones: rounding noise)
+            err = float((gfree - grads[0][k]).abs().max()) / float(grads[0][k].abs().max())
+            assert err <= 2e-5, (k, err)                                             # float-atomic order
 
 
 @pytest.mark.gpu
