@@ -14,6 +14,8 @@ Variants:
             are dropped and the row's live elements re-spread over its 4 lanes: the wave evaluates
             ceil(max_rows(live) / 8) pairs per lane from then on
   lin       the last evaluation is replaced by a first-order update p - r u dtau when the Newton step is below `eps_lin`
+            (BUILT: fused_mfma_kernel.h, SparseMapCfg.lin_tol)
+  halley    a Halley step with f'' estimated from the last two slopes (free), overshoots repaired by Newton from the right
     python tools/solver_sim_r5.py [--alphas 1.7 1.5 2.0] [--batch 2048]"""
 import argparse
 import os
@@ -146,5 +148,97 @@ def main():
                       f"(x{cost(base) / cost(res, comp):.2f})  max|dtau| {dt:.1e}")
 
 
+def solve2(X, alpha, halley=True, eps_lin=0.0, cap=0.5, tol=6e-7, tau_tol=2e-7, maxit=40, first_norm=False):
+    f32=np.float32
+    am1 = f32(alpha - 1); r = f32(1.0)/am1
+    Xs = (X*am1).astype(f32)
+    W,R,F = Xs.shape
+    mx = Xs.max(-1); mean = Xs.mean(-1, dtype=f32)
+    tau = np.maximum(mx-1, mean - f32((1.0/F)**(alpha-1))).astype(f32)
+    active = np.ones((W,R), bool)
+    gen = np.zeros(W, int)
+    pt = np.zeros_like(tau); pD = np.zeros_like(tau); have = np.zeros((W,R), bool)
+    overs = 0
+    lin_pending = np.zeros((W,R), bool)
+    for it in range(maxit):
+        wa = active.any(1)
+        if not wa.any(): break
+        gen += wa
+        t = np.clip(Xs - tau[...,None], 0, None)
+        with np.errstate(all='ignore'):
+            if alpha == 2.0:
+                u = (t>0).astype(f32)
+            else:
+                u = np.where(t>0, np.exp2((r-1)*np.log2(np.where(t>0,t,1))), 0).astype(f32)
+        S = (u*t).sum(-1, dtype=f32); D = (r*u.sum(-1, dtype=f32)).astype(f32)
+        f = S - 1
+        newt = f/np.maximum(D, f32(1e-30))
+        step = newt.copy()
+        if halley:
+            with np.errstate(all='ignore'):
+                f2 = (pD - D)/(tau - pt)            # secant estimate of f'' (>= 0 for convex f)
+                den = 1 - f*f2/(2*D*D)
+                ok = have & np.isfinite(den) & (f2 > 0) & (f > 0)
+                den = np.clip(den, cap, 1.0)
+                step = np.where(ok, newt/den, newt)
+        if first_norm and it == 0:
+            with np.errstate(all='ignore'):
+                stepn = (r*S/D)*(1-np.exp2(-np.log2(np.maximum(S,1e-30))/r))
+            step = np.where(f>0, np.maximum(step, stepn), step)
+        thr = np.maximum(tol, tau_tol*min(1.0, float(am1)/0.7)*D)
+        tn = (tau + step).astype(f32)
+        conv = ~(np.abs(f) > thr) | (tn == tau)
+        act = active & ~conv
+        overs += (active & (f < -thr)).sum()
+        if eps_lin > 0:
+            lin = act & (np.abs(step) < eps_lin)
+            act &= ~lin
+        else:
+            lin = np.zeros_like(act)
+        upd = act | lin
+        pt = np.where(upd, tau, pt); pD = np.where(upd, D, pD); have |= upd
+        tau = np.where(upd, tn, tau).astype(f32)
+        active = act
+    # residual check in float64 at final tau
+    t = np.clip(Xs.astype(np.float64) - tau[...,None].astype(np.float64), 0, None)
+    res = (t**float(r)).sum(-1) - 1
+    return gen.mean(), np.abs(res).max(), overs, np.bincount(gen)
+
+
+
+def support_stats(X, alpha):
+    """supports of the exact root (float64 bisection) and of the kernel's start, per row and per wave (max of 16 rows)"""
+    am1 = alpha - 1
+    r = 1 / am1
+    Xs = (X * np.float32(am1)).astype(np.float64)
+    F = Xs.shape[-1]
+    mx = Xs.max(-1)
+    lo, hi = mx - 1, mx.copy()
+    for _ in range(60):
+        m = (lo + hi) / 2
+        fm = (np.clip(Xs - m[..., None], 0, None) ** r).sum(-1) - 1
+        lo = np.where(fm > 0, m, lo)
+        hi = np.where(fm > 0, hi, m)
+    tau0 = np.maximum(mx - 1, Xs.mean(-1) - (1 / F) ** am1)
+    s_root, s_start = (Xs > lo[..., None]).sum(-1), (Xs > tau0[..., None]).sum(-1)
+    return s_root.mean(), s_root.max(1).mean(), s_start.mean(), s_start.max(1).mean()
+
+
+def more(batch):
+    """the other variants weighed in round 5: support sizes, the first-order finish alone, secant-Halley steps"""
+    X = gates_for("stress", batch)
+    for alpha in (2.0, 1.7, 1.5):
+        a, b, c, d = support_stats(X, alpha)
+        print(f"stress alpha {alpha}: support at the root {a:.1f} of {X.shape[-1]} (slowest row of a wave {b:.1f}); at the start {c:.1f} ({d:.1f})")
+    for alpha in (1.7, 1.5, 1.3, 1.9):
+        base = solve(X, alpha)
+        print(f"stress alpha {alpha}: Newton {base['gen']:.2f} evaluations per pass; first-order finish below eps: "
+              + ", ".join(f"{eps:g}: {solve(X, alpha, eps_lin=eps)['gen']:.2f}" for eps in (1e-5, 3e-5, 1e-4, 3e-4)))
+        for kw in (dict(halley=True), dict(halley=True, eps_lin=1e-4), dict(halley=True, eps_lin=1e-4, first_norm=True)):
+            g = solve2(X, alpha, **kw)
+            print(f"    secant-Halley {kw}: {g[0]:.2f} evaluations, max |residual| {g[1]:.1e}, overshoots {g[2]}")
+
+
 if __name__ == "__main__":
     main()
+    more(1024)
