@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--regime", choices=["fresh", "stress", "both"], default="both",
                     help="fresh = the reference's initialisers (what `value` reports); stress = SURVEY §8c "
                          "sparse-support weights; both = measure both, `value` from fresh")
-    ap.add_argument("--settle-ms", type=float, default=150.0,
+    ap.add_argument("--settle-ms", type=float, default=2500.0,
                     help="untimed run of the step before the warm-up steps, so that the device clocks have settled")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct (ids, vals, out) batches cycled through by the steps (working set > 256 MiB MALL)")
@@ -159,7 +159,10 @@ def settle_clocks(fn, ms, cap_ms=None):
     single chunks on this device scatter by several per cent from one to the next (BENCH_r04: 5.8 % between windows,
     which the round-4 rule — all of the last 8 chunks within 1 % of each other — could not reach in its 3 s cap); a clock
     that is still creeping moves the 8-chunk median by more than 1 % per 8 chunks or it is not worth waiting for.
-    Gives up after `cap_ms` (default 10 x ms).
+    `ms` defaults to 2.5 s (round 5): every process on these boxes runs its first ~2 s of load on a FLAT slower level
+    (105 us per step, then 87 — profiles/r05_bench_n1_with_150ms_settle.json: a plateau test alone leaves the pre-run on
+    that level after 150 ms and the first window after it is 20 % slow; round 4 only got past it because its stricter
+    rule always ran into its 3 s cap).  Gives up after `cap_ms` (default 10 x ms).
     Returns (chunks run, reached the plateau)."""
     if ms <= 0:
         return 0, True
@@ -476,13 +479,13 @@ def main():
             if a.settle_ms > 0:
                 # the same W + K steps from a cold device, for the record (`cold_start` in the line)
                 m["cold"] = window(step_block)[0]
-            n_chunks, flat = settle_clocks(step_block, a.settle_ms, cap_ms=20 * a.settle_ms)
-            settle_info.update(chunks_of_64_steps=n_chunks, plateau_reached=flat, cap_ms=20 * a.settle_ms,
+            n_chunks, flat = settle_clocks(step_block, a.settle_ms, cap_ms=a.settle_ms + 3000.0)
+            settle_info.update(chunks_of_64_steps=n_chunks, plateau_reached=flat, cap_ms=a.settle_ms + 3000.0,
                                spread_of_last_8_chunks=SETTLE_NOISE[0])
             head_windows.append(("clock settle",) + window(step_block))
             m["block"] = None                             # filled from head_windows at the end
         else:
-            settle_clocks(step_block, a.settle_ms)
+            settle_clocks(step_block, min(a.settle_ms, 300.0), cap_ms=1000.0)   # (the device is warm: the head regime ran)
             m["block"] = windows(step_block, 3)
         settle_clocks(step_full, min(a.settle_ms, 50.0), cap_ms=300.0)
         m["full"] = windows(step_full, 3)
@@ -846,7 +849,7 @@ def main():
                                    + ("; no clock-settling pre-run; " if a.settle_ms <= 0 else
                                       f"; device clocks settled to a plateau by >= {a.settle_ms:g} ms of the same step, untimed; "
                                       if settle_info.get("plateau_reached") else
-                                      f"; the clock-settling pre-run hit its {20 * a.settle_ms:g} ms cap WITHOUT reaching a "
+                                      f"; the clock-settling pre-run hit its {a.settle_ms + 3000.0:g} ms cap WITHOUT reaching a "
                                       f"plateau (see clock_settle); ") +
                                    f"value = median of {len(win_ms)} windows of {a.steps} steps spread over the process",
                        "global_batch": world * a.batch, "parallelism": parallelism, "clock_settle_ms": a.settle_ms,
