@@ -213,8 +213,8 @@ class RowShardedTable:
         self._overflow = None     # device flag of the fixed protocol, OR-ed by every lookup since the last check
         self.dedup = dedup        # True / False / "auto" (de-duplicate when the batch is >= 1/8 of the table)
         self.micro_batches = 1    # > 1: sharded_arm_block overlaps the exchange of slice m+1 with the kernel of slice m
-        self.whole_shard = "auto" # fixed protocol: all-gather the shards when the de-duplicated slot would be the whole
-                                  # shard anyway ("auto"), always (True), never (False)
+        self.whole_shard = "auto" # fixed protocol: all-gather the shards when the de-duplicated slot would be (3/4 of) the
+                                  # whole shard anyway ("auto"), always (True), never (False)
         self._table_ag = None     # the shard padded to ceil(nfeat / R) rows (all-gather needs equal pieces); dropped
                                   # whenever `table_local` is assigned (the property below)
         self.last_path = None     # which exchange the last lookup used: "whole_shards" | "fixed" | "exact"
@@ -402,7 +402,9 @@ class RowShardedTable:
             self.slot_distinct = None
         cap = self.capacity(self._agreed_distinct(flat, n_slot) if dedup else n_slot, dedup)
         L = (self.nfeat + R - 1) // R
-        if self.whole_shard is True or (self.whole_shard == "auto" and dedup and cap >= L):
+        # request lists that ask for most of every shard cost more than shipping the shards (4 bytes of index per row on top
+        # of the row, the routing passes, the owner-side gather): from 3/4 of a shard on, the owners all-gather instead
+        if self.whole_shard is True or (self.whole_shard == "auto" and dedup and 4 * cap >= 3 * L):
             self.last_path = "whole_shards"
             return self._lookup_whole_shards(flat, id_status)
         self.last_path = "fixed"
