@@ -615,11 +615,12 @@ class _MLP(nn.Module):
     def eval_path(self):
         """which code runs the eval-mode head (reported by bench.py)"""
         if self.hip_head and self._hip_plan() is not None:
+            last = "armnet_linear_small_f32" if self._dims[3] <= 16 else "armnet_linear_bf16x3_f32"
             if self._dims[1] == 0:
-                return "armnet_linear_small_f32: the head is one Linear (nlayers = 0), a plain fp32 HIP kernel"
+                return f"{last}: the head is one Linear (nlayers = 0)" + (", a plain fp32 HIP kernel" if self._dims[3] <= 16 else "")
             return ("armnet_mlp_head_f32: ONE HIP kernel, bf16x3-split operands on v_mfma_f32_32x32x16_bf16 "
                     "(6 cross products, fp32 accumulate), hidden layers chained in registers"
-                    + ("" if self._dims[3] == 1 else "; final Linear with several outputs by armnet_linear_small_f32"))
+                    + ("" if self._dims[3] == 1 else f"; final Linear with several outputs by {last}"))
         return "torch/hipBLASLt fp32 GEMMs, BatchNorm folded into the weights, bias+ReLU epilogue"
 
     def invalidate(self):
@@ -639,7 +640,7 @@ class _MLP(nn.Module):
         the last hidden layer the first slice writes its share of the final Linear (has_final 1) and the others add
         theirs (has_final 2)."""
         ninput, nlayers, nhid, noutput = self._dims
-        if noutput < 1 or noutput > 16:
+        if noutput < 1:
             return None
         if nlayers == 0:
             return []                                  # one Linear(ninput, noutput): armnet_linear_small_f32 alone (round 4)
@@ -716,9 +717,7 @@ class _MLP(nn.Module):
         B = x.shape[0]
         hidden, last = self._groups()
         if nlayers == 0:                               # layers.py:79-80: the MLP is one Linear
-            y = torch.empty(B, noutput, device=x.device, dtype=torch.float32)
-            native.linear_small(x, last.weight.detach().contiguous(), last.bias.detach(), y)
-            return y
+            return self._final_linear(x, last)
         NP = (nhid + 15) // 16 * 16
         cur, cur_layer = x, 0                          # activations feeding hidden layer `cur_layer`
         nxt = None
@@ -742,10 +741,38 @@ class _MLP(nn.Module):
                     nxt = torch.zeros(B, NP, device=x.device, dtype=torch.float32)   # pad columns stay zero
                 native.mlp_head(B, K0, n1 - n0, n, 0, cur, blob, nxt[:, n0:])
         if noutput != 1:                               # layers.py:86-87 with several outputs, on the last hidden activations
-            y = torch.empty(B, noutput, device=x.device, dtype=torch.float32)
-            native.linear_small(nxt[:, :nhid], last.weight.detach().contiguous(), last.bias.detach(), y)
-            return y
+            return self._final_linear(nxt[:, :nhid], last)
         return logits.view(B, 1)
+
+    def _final_linear(self, x, last):
+        """the head's last Linear(K, noutput) alone (layers.py:79-80 with nlayers == 0, layers.py:86-87 with several outputs):
+        up to 16 outputs one wave per row in plain fp32 (armnet_linear_small_f32), more on the matrix cores
+        (armnet_linear_bf16x3_f32, slices of 256 outputs; round 5 — the reference builds no such head for ARM-Net, but
+        `noutput` is a constructor argument, armnet_1h.py:44)"""
+        B, K = x.shape
+        N = self._dims[3]
+        if N <= 16:
+            y = torch.empty(B, N, device=x.device, dtype=torch.float32)
+            native.linear_small(x, last.weight.detach().contiguous(), last.bias.detach(), y)
+            return y
+        KP = (K + 15) // 16 * 16                       # the kernel reads whole 16-float k-steps of every row
+        if x.stride(1) != 1 or (B > 1 and x.stride(0) < KP) or (B == 1 and KP != K):
+            x = torch.nn.functional.pad(x, (0, KP - K))[:, :K]
+        key = tuple((t.data_ptr(), t._version) for t in (last.weight, last.bias))
+        if self._pack_key.get("final") != key:         # packed bf16 planes of the final Linear, per slice of 256 outputs
+            blobs = []
+            with torch.no_grad():
+                for n0 in range(0, N, 256):
+                    n1 = min(N, n0 + 256)
+                    blob = torch.zeros(native.mlp_packed_bytes(K, n1 - n0, 1), device=x.device, dtype=torch.uint8)
+                    native.mlp_pack_layer(K, n1 - n0, 1, 0, last.weight.detach()[n0:n1].contiguous(),
+                                          last.bias.detach()[n0:n1].contiguous(), None, blob)
+                    blobs.append((n0, n1, blob))
+            self._packed["final"], self._pack_key["final"] = blobs, key
+        y = torch.empty(B, N, device=x.device, dtype=torch.float32)
+        for n0, n1, blob in self._packed["final"]:
+            native.linear_bf16x3(x, blob, y[:, n0:], K, n1 - n0)
+        return y
 
     def _fold(self):
         mods = list(self.mlp)
