@@ -411,7 +411,7 @@ class RowShardedTable:
         # armnet_shard_route_fixed covers 32-bit positions: R * cap, n and (with de-duplication) the padded position map
         # below 2^31, nfeat below 2^32; beyond that the round-3 pair route + pad_route (64-bit throughout) serves the step
         # (round-4 advisor finding: the entry point's UNSUPPORTED used to surface as an error)
-        fits = R * cap < 2 ** 31 and n < 2 ** 31 and self.nfeat < 2 ** 32 and (
+        fits = R * cap + N < 2 ** 31 and n < 2 ** 31 and self.nfeat < 2 ** 32 and (
             not dedup or R * ((L + 1023) // 1024 * 1024) < 2 ** 31)
         if n > 0 and self.fused_route and fits and hasattr(self.ops, "route_fixed"):
             # the slots directly (round 4): no back-to-back layout in between, no separate pad pass
@@ -428,8 +428,9 @@ class RowShardedTable:
             else:
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status, **hot)
         elif N:
-            raise native.ArmnetNativeError("hot_rows needs the fused fixed-protocol route (fused_route = True and an ops "
-                                           "object with route_fixed)")
+            raise native.ArmnetNativeError("hot_rows needs the fused fixed-protocol route: fused_route = True, an ops object with "
+                                           "route_fixed, and positions that fit 32 bits (R * cap + hot_rows < 2^31, "
+                                           "nfeat < 2^32)")
         else:
             if n == 0:                                     # an empty slice still takes part in the exchanges
                 counts = torch.zeros(R, device=dev, dtype=torch.int32)
