@@ -178,10 +178,14 @@ class HipShardOps:
         return perm
 
 
-def slot_capacity(n, R, nfeat, dedup, capacity_factor=1.25):
-    """slot size (entries per owner) of the fixed-capacity exchange for n routed lookups over R ranks"""
+def slot_capacity(n, R, nfeat, dedup, capacity_factor=1.25, upper=None):
+    """slot size (entries per owner) of the fixed-capacity exchange for n routed lookups over R ranks.  upper: a number no
+    owner can be asked for more than (the step's total lookups) — only when n IS such a bound; an ESTIMATE of the routed
+    lookups (the cold ones with hot rows, the distinct ones with de-duplication: measured on the first step) is not, and a
+    slot clamped to it overflowed on the first step that exceeded the first one (one rank, round 5)"""
     cap = int(capacity_factor * n / R) + 4 * int((n / R) ** 0.5) + 16
-    cap = min(cap, max(n, 1))
+    if upper is not None:
+        cap = min(cap, max(int(upper), 1))
     if dedup:
         cap = min(cap, (nfeat + R - 1) // R)
     return max(cap, 1)
@@ -336,10 +340,10 @@ class RowShardedTable:
             self.slot_distinct = d
         return min(int(self.slot_distinct), int(n_slot))
 
-    def capacity(self, n, dedup):
+    def capacity(self, n, dedup, upper=None):
         """slot size of the fixed protocol for n lookups: the mean n/R plus the slack factor and a few standard
-        deviations for small batches; with de-duplication never more than the owner's shard"""
-        return slot_capacity(n, self.world, self.nfeat, dedup, self.capacity_factor)
+        deviations for small batches; with de-duplication never more than the owner's shard; never more than `upper`"""
+        return slot_capacity(n, self.world, self.nfeat, dedup, self.capacity_factor, upper)
 
     def overflowed(self):
         """True on every rank if a slot of the fixed protocol overflowed on ANY rank since the last call (one tiny
@@ -400,7 +404,8 @@ class RowShardedTable:
         dedup = (8 * n_slot >= self.nfeat) if self.dedup == "auto" else bool(self.dedup)
         if first:
             self.slot_distinct = None
-        cap = self.capacity(self._agreed_distinct(flat, n_slot) if dedup else n_slot, dedup)
+        # (n_slot bounds what one owner can be asked for only when it counts ALL lookups of the agreed step)
+        cap = self.capacity(self._agreed_distinct(flat, n_slot) if dedup else n_slot, dedup, upper=None if N else n_slot)
         L = (self.nfeat + R - 1) // R
         # request lists that ask for most of every shard cost more than shipping the shards (4 bytes of index per row on top
         # of the row, the routing passes, the owner-side gather): from 3/4 of a shard on, the owners all-gather instead

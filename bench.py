@@ -606,7 +606,8 @@ def main():
             else:
                 n_slot = sh.slot_lookups or n_lk
                 dd = (8 * n_slot >= a.nfeat) if sh.dedup == "auto" else bool(sh.dedup)
-                cap = sh.capacity(min(sh.slot_distinct or n_slot, n_slot) if dd else n_slot, dd)
+                cap = sh.capacity(min(sh.slot_distinct or n_slot, n_slot) if dd else n_slot, dd,
+                                  upper=None if sh.hot_rows else n_slot)
                 per_peer = cap * (E4 + 4)                    # the rows it asked for + the request list it answers
                 mode["slot_rows"] = cap
             mode["ingress_bytes_per_rank_per_step"] = per_peer * (R - 1)

@@ -29,7 +29,7 @@ bash tools/sweep.sh
 echo
 echo "# the row-sharded lookup path on ONE rank (bench.py --shard rows ...): headline shape and configs[3]; uniform and skewed ids; hot rows"
 P='import sys,json
-d=json.loads(sys.stdin.readlines()[-1]); h=d.get("hot_rows",{}); print("%-78s %7.1f us/step %7.1f Msamp/s  full fwd %7.1f Msamp/s  path %s  ingress@8 %s" % (sys.argv[1], d["ms_per_step"]*1e3, d["value"]/1e6, d["full_forward"]["value"]/1e6, d.get("row_sharded_path"), json.dumps(h.get("ingress_bytes_per_rank_per_step_at_8_ranks"))))'
+d=json.loads(sys.stdin.readlines()[-1]); h=d.get("hot_rows",{}); print("%-78s %7.1f us/step %7.1f Msamp/s  full fwd %7.1f Msamp/s  path %s  overflow %s  ingress@8 %s" % (sys.argv[1], d["ms_per_step"]*1e3, d["value"]/1e6, d["full_forward"]["value"]/1e6, d.get("row_sharded_path"), d.get("row_sharded_overflow"), json.dumps(h.get("ingress_bytes_per_rank_per_step_at_8_ranks"))))'
 for v in "--shard rows" "--shard rows --whole-shard off" "--shard rows --whole-shard off --dedup off" \
          "--shard rows --ids zipf --whole-shard off" "--shard rows --ids zipf --whole-shard off --hot-rows 65536" \
          "--shard rows --ids zipf --whole-shard off --dedup off" "--shard rows --ids zipf --whole-shard off --dedup off --hot-rows 65536" \
