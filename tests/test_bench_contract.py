@@ -186,3 +186,21 @@ def test_one_rank_row_sharded_line_prices_the_hot_rows():
     assert h["rows"] == 65536 and 0.1 < h["cold_fraction"] < 0.3
     io = h["ingress_bytes_per_rank_per_step_at_8_ranks"]
     assert io["cut"] >= 3.0 and io["with"] * 3 <= io["without"]
+
+
+@pytest.mark.gpu
+def test_two_rank_line_with_hot_rows_under_skewed_ids():
+    """the N > 1 flow with `--ids zipf --hot-rows 4096` (two ranks on the one GPU, gloo): shard_embedding's hot-row
+    all-gather, the hot route and the distinct-sized slots inside bench.py's own sharded measurement; nothing overflows"""
+    env = dict(os.environ, ARMNET_BENCH_BACKEND="gloo", ARMNET_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--regime", "fresh", "--no-config4", "--no-config5",
+                        "--ids", "zipf", "--hot-rows", "4096", "--settle-ms", "50"],
+                       cwd=ROOT, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = _one_json_line(p.stdout)
+    rs = d["row_sharded"]
+    assert "error" not in rs, rs
+    assert d["n_gpus"] == 2 and d["value"] == rs["value"] > 0 and rs["ids"] == "zipf"
+    assert "fixed" in rs["by_exchange"] and not rs["by_exchange"]["fixed"].get("overflow")
