@@ -436,5 +436,22 @@ def test_hot_rows_on_one_rank_without_a_process_group():
         rows, perm = shard.lookup(ids)
         assert torch.equal(rows[perm.long()].view(50, 7, E), table[ids])
         assert torch.equal(rows[-512:], table[:512]) and not shard.overflowed()
+        # later steps drawn from the same stream have a few more or fewer cold / distinct ids than the first one: the slots
+        # are sized from the first step's ESTIMATE plus slack and must not be clamped to it (round 5: they were, on one rank)
+        for seed in range(4, 10):
+            ids2 = _zipf_ids(nfeat, (50, 7), seed)
+            rows2, perm2 = shard.lookup(ids2)
+            assert torch.equal(rows2[perm2.long()].view(50, 7, E), table[ids2])
+        assert not shard.overflowed()
     with pytest.raises(ValueError):
         RowShardedTable(table, nfeat, None, ops=NumpyShardOps(), hot_rows=nfeat + 1)
+
+
+def test_slot_capacity_clamps_only_to_a_true_upper_bound():
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    from armnet_hip.sharded import fixed_ingress_bytes, slot_capacity
+    assert slot_capacity(1000, 1, 10**6, False, 1.25, upper=1000) == 1000          # all lookups of the step: nobody can ask for more
+    assert slot_capacity(1000, 1, 10**6, False, 1.25) > 1250                          # an estimate: slack on top, no clamp
+    assert slot_capacity(10**6, 8, 10**6, True, 1.25) == 125000                       # de-duplicated: never more than the shard
+    assert fixed_ingress_bytes(2_555_904, 8, 10**6, 16, dedup=False) == slot_capacity(2_555_904, 8, 10**6, False) * 68 * 7
+    assert fixed_ingress_bytes(2_555_904, 8, 10**6, 16, dedup=True, n_distinct=430_000) < fixed_ingress_bytes(2_555_904, 8, 10**6, 16, dedup=True)
