@@ -784,7 +784,15 @@ def main():
                   # the bytes the fabric really moves (PMC, 128 bytes per read request: a random 64-byte row costs a
                   # whole 128-byte line) over the same kernel time, against the same 8 TB/s
                   "hbm_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
+            # requests the L2 sends to the fabric per launch, modelled: one 128-byte line fill per 128 bytes of a random row (a
+            # 64-byte row costs a whole one), ids / values as streams of line fills, output as 64-byte write requests — the
+            # counters of profiles/r05_*_rocprof_summary.txt agree to 3 % (headline: 2.72 M + 2.10 M measured).  A gather-only
+            # kernel sustains 47 G such requests per second from HBM, 55 G from the Infinity Cache
+            n_req = (a.batch * a.nfield * ((a.nemb * 4 + 127) // 128) + a.batch * a.nfield * 12 // 128
+                     + a.batch * write_b // 64)
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "fabric_requests": {"per_launch_model": n_req, "giga_per_s": n_req / (k_ms * 1e-3) / 1e9,
+                                        "gather_only_kernel_giga_per_s": {"hbm": 47.0, "infinity_cache": 55.0}},
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tag,
                     # PMC counters cannot be read from inside the timed process: `traffic` is the committed rocprofv3
                     # --pmc pass for this workload AND these kernel sources (null otherwise), not a measurement of this run
