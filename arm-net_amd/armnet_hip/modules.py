@@ -602,6 +602,8 @@ class _MLP(nn.Module):
         self._folded = None
         self.fold_eval = True
         self.hip_head = True           # eval-mode inference through armnet_mlp_head_f32 where it has a kernel
+        self.bf16x3 = False            # True: force the bf16 x 3 operand split (six products; the rounds 2-5 kernel) instead
+                                       # of fp16 x 2 (three products, in-kernel fallback to bf16 x 3 out of the fp16 range)
         self.mfma_train = False        # training-mode Linear forward / dX through armnet_linear_bf16x3_f32 (round 5).  OFF:
                                        # measured 2.13 ms against 2.09 ms per step at B = 65 536 and 0.94 against 0.75 ms
                                        # graphed at B = 4 096 (profiles/r05_train_step_times.txt) — one layer per launch
@@ -618,8 +620,10 @@ class _MLP(nn.Module):
             last = "armnet_linear_small_f32" if self._dims[3] <= 16 else "armnet_linear_bf16x3_f32"
             if self._dims[1] == 0:
                 return f"{last}: the head is one Linear (nlayers = 0)" + (", a plain fp32 HIP kernel" if self._dims[3] <= 16 else "")
-            return ("armnet_mlp_head_f32: ONE HIP kernel, bf16x3-split operands on v_mfma_f32_32x32x16_bf16 "
-                    "(6 cross products, fp32 accumulate), hidden layers chained in registers"
+            split = ("bf16x3-split operands on v_mfma_f32_32x32x16_bf16 (6 cross products, fp32 accumulate)" if self.bf16x3 else
+                     "fp16x2-split operands on v_mfma_f32_32x32x16_f16 (3 cross products, fp32 accumulate; blocks whose "
+                     "inputs leave the fp16 range redo in bf16x3 inside the launch)")
+            return (f"armnet_mlp_head_f32: ONE HIP kernel, {split}, hidden layers chained in registers"
                     + ("" if self._dims[3] == 1 else f"; final Linear with several outputs by {last}"))
         return "torch/hipBLASLt fp32 GEMMs, BatchNorm folded into the weights, bias+ReLU epilogue"
 
@@ -720,6 +724,7 @@ class _MLP(nn.Module):
             return self._final_linear(x, last)
         NP = (nhid + 15) // 16 * 16
         cur, cur_layer = x, 0                          # activations feeding hidden layer `cur_layer`
+        flags = native.MLP_F_BF16X3 if self.bf16x3 else 0
         nxt = None
         add = logits is not None
         for first, K0, n, has_final, n0, n1, blob in self._pack(ens):
@@ -735,11 +740,11 @@ class _MLP(nn.Module):
             if has_final:
                 if logits is None:
                     logits = torch.empty(B, device=x.device, dtype=torch.float32)
-                native.mlp_head(B, K0, n1 - n0, n, has_final, cur, blob, logits)
+                native.mlp_head(B, K0, n1 - n0, n, has_final, cur, blob, logits, flags)
             else:
                 if nxt is None:
                     nxt = torch.zeros(B, NP, device=x.device, dtype=torch.float32)   # pad columns stay zero
-                native.mlp_head(B, K0, n1 - n0, n, 0, cur, blob, nxt[:, n0:])
+                native.mlp_head(B, K0, n1 - n0, n, 0, cur, blob, nxt[:, n0:], flags)
         if noutput != 1:                               # layers.py:86-87 with several outputs, on the last hidden activations
             return self._final_linear(nxt[:, :nhid], last)
         return logits.view(B, 1)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
@@ -37,7 +37,7 @@ EXPORTS = (
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
     "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
-    "armnet_linear_bf16x3_f32",
+    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32",
 )
 
 _lib = None
@@ -493,7 +493,10 @@ def linear_small(x, W, bias, out, scale=1.0, accumulate=False):
                                              int(bool(accumulate)), _stream()))
 
 
-def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
+MLP_F_BF16X3 = 0x1
+
+
+def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out, flags=0):
     """x: [B, >= K0] float32 with unit inner stride whose row stride covers 16 * ceil(K0 / 16) floats (columns past K0
     readable and finite); out: [B] logits (has_final: 1 = write, 2 = add this slice's share) or [B, >= nhid] hidden
     activations (a column slice of a wider buffer qualifies)"""
@@ -504,9 +507,9 @@ def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out):
     ldx = x.stride(0) if B > 1 else max(x.stride(0), x.shape[1])
     ldo = 0 if has_final else (out.stride(0) if B > 1 else max(out.stride(0), out.shape[1]))
     with _on(x, packed, out):
-        check(load().armnet_mlp_head_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(has_final),
-                                         _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
-                                         _stream()))
+        check(load().armnet_mlp_head_ex_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(has_final),
+                                            _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
+                                            ctypes.c_uint32(flags), _stream()))
 
 
 def linear_bf16x3(x, packed, out, K, N):

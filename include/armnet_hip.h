@@ -36,7 +36,7 @@ extern "C" {
  *               armnet_gather_map_stats_f32, armnet_bn_bwd_scatter_f32
  *   5  round 5: hot-row replication of the row-sharded lookup (armnet_shard_route_fixed_hot, _perm_hot,
  *               armnet_shard_gather_perm_hot_f32); armnet_linear_bf16x3_f32 (the training head's GEMMs) */
-#define ARMNET_ABI_VERSION 5
+#define ARMNET_ABI_VERSION 6
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
@@ -434,8 +434,8 @@ int armnet_gc_fused_bwd_f32(int64_t B, int F, int E, int O, float alpha, int n_i
  *   armnet_mlp_pack_layer_f32   parameter-only precompute (re-run when weights change), one call per layer:
  *       slot 0: first hidden layer  W [nhid, K0],  slot 1: second hidden layer W [nhid, nhid],
  *       slot 2: final Linear W [1, nhid], b [1].   bn_* = the BatchNorm1d behind the Linear (NULL: none):
- *       W' = W * s, b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps); W' is then split into bf16
- *       hi/mid/lo (round-to-nearest) in the kernel's operand order.
+ *       W' = W * s, b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps); W' is then split into fp16 hi/lo of
+ *       the row-scaled weight AND bf16 hi/mid/lo (round-to-nearest) in the kernel's operand order.
  *   armnet_mlp_head_f32         x [B, K0] (row stride ldx floats) -> has_final ? out [B] (the logits, layers.py:88)
  *                                                                              : out [B, nhid] (post-ReLU activations,
  *                                                                                row stride ldo floats)
@@ -475,6 +475,17 @@ int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const fl
                               const float* bn_running_var, float bn_eps, void* packed, void* stream);
 int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final, const float* x, int64_t ldx,
                         const void* packed, float* out, int64_t ldo, void* stream);
+/*
+ * Round 6: the head's operand split.  Default (armnet_mlp_head_f32 = flags 0): fp16 x 2 — activations and row-scaled
+ * weights as hi + lo fp16 parts (round to nearest), THREE cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate,
+ * exact power-of-two rescale — with an in-kernel range vote: a block whose first-layer inputs leave the fp16 range
+ * (|x| > 4 062, inf) redoes its samples with the bf16 x 3 split (six products) inside the same launch.
+ * ARMNET_MLP_F_BF16X3 forces the bf16 x 3 split for every block (the rounds 2-5 kernel; A/B and bisecting).
+ * Either way the result matches models/layers.py:68-88 evaluated in fp32 to fp32-GEMM class error.
+ */
+#define ARMNET_MLP_F_BF16X3 0x1u
+int armnet_mlp_head_ex_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final, const float* x, int64_t ldx,
+                           const void* packed, float* out, int64_t ldo, uint32_t flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 """armnet_mlp_head_f32: the eval-mode prediction head models/layers.py:68-88 as one HIP kernel on the
-bf16 matrix cores (3-way bf16 split, six cross products, fp32 accumulate).  First gate: logits within 1e-5 of a
+16-bit matrix cores (round 6: fp16 x 2 split, three cross products, in-kernel fallback to the bf16 x 3 split with six;
+fp32 accumulate).  First gate: logits within 1e-5 of a
 float64 evaluation of the same nn.Sequential, elementwise — the fp32 hipBLASLt path is held to the same bar beside it
 so the two error levels can be compared."""
 import numpy as np
@@ -84,7 +85,67 @@ def test_mlp_head_matches_float64_evaluation(K0, nlayers, nhid, B):
     assert e_hip <= 1.0, f"worst element at {e_hip:.3f} x the 1e-5 bar (hipBLASLt fp32 path: {e_blas:.3f} x)"
 
 
-@pytest.mark.parametrize("scale", [1e-3, 30.0, 4e3])
+@pytest.mark.parametrize("K0,nlayers,nhid", [(512, 2, 256), (2048, 2, 256), (704, 2, 256), (320, 2, 32), (100, 3, 64), (1280, 2, 500)])
+def test_both_operand_splits_sit_at_the_fp32_gemm_error_level(K0, nlayers, nhid):
+    """round 6: fp16 x 2 (three products, the default) and bf16 x 3 (six, `bf16x3 = True` / ARMNET_MLP_F_BF16X3) against a
+    float64 evaluation, the fp32 hipBLASLt path beside them"""
+    B = 2000
+    m = _make_head(K0, nlayers, nhid, seed=K0 + nhid).to(DEV)
+    x = (torch.rand(B, K0, generator=torch.Generator().manual_seed(5)) * 3.0 - 1.0).to(DEV)
+    want = _ref64(m, x).cpu().numpy()
+    err = {}
+    with torch.no_grad():
+        err["f16x2"] = float(np.max(np.abs(m(x).cpu().numpy() - want)))
+        m.bf16x3 = True
+        assert "bf16x3" in m.eval_path()
+        err["bf16x3"] = float(np.max(np.abs(m(x).cpu().numpy() - want)))
+        m.hip_head = False
+        err["blas"] = float(np.max(np.abs(m(x).cpu().numpy() - want)))
+    print(f"K0={K0} nlayers={nlayers} nhid={nhid}: " + ", ".join(f"{k} {v:.2e}" for k, v in err.items()))
+    scale = max(1.0, float(np.abs(want).max()))
+    assert err["f16x2"] <= TOL * scale and err["bf16x3"] <= TOL * scale
+    assert err["f16x2"] <= 2.0 * max(err["blas"], err["bf16x3"], 1e-7 * scale)
+
+
+@pytest.mark.parametrize("B", [300, 40000])
+def test_blocks_outside_the_fp16_range_redo_in_bf16x3(B):
+    """the reference has no clamp behind exp (armnet_1h.py:86): a first-layer input may be anything.  A block that meets
+    |x| > 4 062, inf or -inf runs the bf16 x 3 split — bit-equal to the forced bf16 x 3 launch for its samples —, every other
+    block keeps its fp16 x 2 result; a NaN poisons its own sample only"""
+    K0, nlayers, nhid = 512, 2, 256
+    m = _make_head(K0, nlayers, nhid, seed=9).to(DEV)
+    x = (torch.rand(B, K0, generator=torch.Generator().manual_seed(B)) * 3.0 - 1.0).to(DEV)
+    blk = 128 if B <= 32768 else 256
+    with torch.no_grad():
+        plain = m(x).clone()
+        xb = x.clone()
+        xb[5, 17] = 5.0e3                     # block 0
+        xb[B - 1, 500] = -7.0e4               # last block
+        xb[blk + 3, 0] = float("nan")         # block 1: stays fp16 x 2
+        auto = m(xb).clone()
+        m.bf16x3 = True
+        forced = m(xb).clone()
+        m.bf16x3 = False
+        want = _ref64(m, xb)
+    last0 = (B - 1) // blk * blk
+    redo = torch.zeros(B, dtype=torch.bool, device=DEV)
+    redo[:blk] = True
+    redo[last0:] = True
+    assert torch.equal(auto[redo], forced[redo])
+    keep = ~redo
+    keep[blk + 3] = False
+    assert torch.equal(auto[keep], plain[keep])
+    assert bool(torch.isnan(auto[blk + 3]).all()) and bool(torch.isfinite(auto[keep]).all())
+    fin = torch.isfinite(want[:, 0])
+    assert elem_excess(auto[fin].cpu().numpy(), want[fin].cpu().numpy(), TOL) <= 1.0
+    with torch.no_grad():                     # +inf: non-finite logits for that sample, as in the reference
+        xi = x.clone()
+        xi[7, 3] = float("inf")
+        yi = m(xi)
+    assert not bool(torch.isfinite(yi[7]).any()) and torch.equal(yi[blk:], plain[blk:])
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 30.0, 4e3, 1e5])
 def test_mlp_head_keeps_fp32_accuracy_over_the_input_range(scale):
     """inputs from 1e-3 to the wide-exponent regime's 4e3: the bf16 split has fp32's exponent range, so the error
     relative to the magnitude of the terms is the same at every scale; compared with the fp32 GEMM path's own error"""
