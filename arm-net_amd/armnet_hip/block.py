@@ -18,6 +18,48 @@ def _require_cuda(t, what):
             "Move the model and the batch to the same device (model.cuda(), batch['id'].cuda(), ...).")
 
 
+class IdStatus:
+    """The out-of-range-id report of one module, DEFERRED — the shape of the reference's GPU behaviour: nn.Embedding on a
+    device (models/layers.py:20) raises nothing at the call, a device-side assert surfaces at a later synchronisation, and
+    train.py:117-121 never pays a sync for it.  One int32 word in PINNED HOST memory (mapped into every device): a kernel
+    that meets an id outside [0, nfeat) stores 1 into it (the id reads row 0: memory-safe, the sample's output is
+    garbage); the host reads the word WITHOUT touching the device —
+        * at the module's next call (`raise_if_set`): IndexError for an earlier call whose kernels have finished,
+        * at `poll()`: after synchronising the device — the answer for everything enqueued so far,
+        * `check_ids = "sync"` on the module polls behind every call (the rounds 1-5 behaviour: one host sync per forward).
+    No allocation, fill, copy or `.item()` per call."""
+
+    def __init__(self):
+        self._word = None
+
+    def word(self):
+        if self._word is None:
+            self._word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._word
+
+    def raise_if_set(self):
+        w = self._word
+        if w is not None and int(w[0]) != 0:                 # a host-memory read
+            w.zero_()
+            raise IndexError("index out of range in self")
+
+    def poll(self, device=None):
+        if self._word is not None:
+            torch.cuda.synchronize(device)
+            self.raise_if_set()
+
+
+def _id_mode(check_ids, status):
+    """(flag word for the kernels | None, poll behind the call?) of a `check_ids` setting: False / None = unchecked,
+    True = deferred (IdStatus), "sync" = IndexError before the call returns"""
+    if not check_ids:
+        return None, False
+    if status is None:                                       # a stand-alone call without a module: nothing to defer to
+        status, check_ids = IdStatus(), "sync"
+    status.raise_if_set()
+    return status, check_ids == "sync"
+
+
 class ArmBlockParams:
     """Folded parameters of one ARM block (q_fold, bn_scale, bn_shift), refreshed when the
     source tensors change (tracked by their autograd version counters and storage pointers)."""
@@ -44,10 +86,11 @@ class ArmBlockParams:
 
 
 def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alpha, n_iter=50,
-                      write_clamped_vals=True, check_ids=True, flags=0, rows=None, out=None):
+                      write_clamped_vals=True, check_ids=True, flags=0, rows=None, out=None, status=None):
     """Fused a2..a9.  Returns out [B, O, E] (post-BN).  ``vals`` is clamped in place
-    when write_clamped_vals (the reference's side effect, armnet_1h.py:81).  With check_ids an
-    out-of-range id raises IndexError like the reference's CPU path (costs one host sync)."""
+    when write_clamped_vals (the reference's side effect, armnet_1h.py:81).  check_ids: the kernel's range test of the
+    ids is on; an out-of-range id raises IndexError — through `status` (an IdStatus: deferred to the owner's next call /
+    poll(), no host sync here) or, with check_ids == "sync" or no `status`, before this call returns (one host sync)."""
     _require_cuda(vals, "x['value']")
     if not vals.is_contiguous() or vals.dtype != torch.float32:
         raise native.ArmnetNativeError("x['value'] must be a contiguous float32 tensor (clamped in place)")
@@ -65,16 +108,16 @@ def arm_block_forward(ids, vals, table, q_fold, values, bn_scale, bn_shift, alph
         return out
     _require_cuda(ids, "x['id']")
     ids = ids if ids.is_contiguous() else ids.contiguous()
-    status = torch.zeros(1, device=vals.device, dtype=torch.int32) if check_ids else None
+    status, sync = _id_mode(check_ids, status)
     native.fused_fwd(B, F, E, O, alpha, n_iter, fl, ids, vals, table.detach(), q_fold, values2d, bn_scale,
-                     bn_shift, out, status)
-    if check_ids and int(status.item()) != 0:
-        raise IndexError("index out of range in self")
+                     bn_shift, out, None if status is None else status.word())
+    if sync:
+        status.poll(vals.device)
     return out
 
 
-def embedding_forward(ids, vals, table, check_ids=True):
-    """layers.py:15-21 — table[ids] * vals.unsqueeze(2) -> [B, F, E]."""
+def embedding_forward(ids, vals, table, check_ids=True, status=None):
+    """layers.py:15-21 — table[ids] * vals.unsqueeze(2) -> [B, F, E].  check_ids / status: see arm_block_forward."""
     if host_ops.on_host(ids, table) and (vals is None or not vals.is_cuda):
         return host_ops.embedding(ids, vals, table)                  # host tensors: the reference's own ops
     _require_cuda(ids, "x['id']")
@@ -89,10 +132,10 @@ def embedding_forward(ids, vals, table, check_ids=True):
         v = vals.contiguous()
         if v.dtype != torch.float32:
             v = v.float()
-    status = torch.zeros(1, device=ids.device, dtype=torch.int32) if check_ids else None
-    native.gather_scale(n, E, ids_c, v, table.detach(), out, status)
-    if check_ids and int(status.item()) != 0:
-        raise IndexError("index out of range in self")
+    status, sync = _id_mode(check_ids, status)
+    native.gather_scale(n, E, ids_c, v, table.detach(), out, None if status is None else status.word())
+    if sync:
+        status.poll(ids.device)
     return out
 
 

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import host_ops, native
-from .block import ArmBlockParams, _require_cuda, arm_block_forward, embedding_forward, entmax_forward
+from .block import ArmBlockParams, IdStatus, _require_cuda, arm_block_forward, embedding_forward, entmax_forward
 
 
 class _GatherScaleFn(torch.autograd.Function):
@@ -19,7 +19,8 @@ class _GatherScaleFn(torch.autograd.Function):
     def forward(ctx, table, ids, vals, check_ids):
         ctx.save_for_backward(ids, vals)
         ctx.nfeat = table.shape[0]
-        return embedding_forward(ids, vals, table, check_ids=check_ids)
+        check_ids, status = check_ids if isinstance(check_ids, tuple) else (check_ids, None)
+        return embedding_forward(ids, vals, table, check_ids=check_ids, status=status)
 
     @staticmethod
     def backward(ctx, g):
@@ -38,8 +39,9 @@ class _ArmBlockFn(torch.autograd.Function):
     def forward(ctx, table, bilinear_w, query, values, ids, vals, cfg):
         variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
         qf, one, zero = _fold_train(variant, K, H, E, D, bilinear_w, query)
+        check_ids, status = check_ids if isinstance(check_ids, tuple) else (check_ids, None)
         z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
-                              write_clamped_vals=True, check_ids=check_ids, flags=flags)
+                              write_clamped_vals=True, check_ids=check_ids, flags=flags, status=status)
         ctx.save_for_backward(table, bilinear_w, query, values, ids, vals, qf, z)
         ctx.cfg = cfg
         return z
@@ -111,8 +113,9 @@ class _ArmBlockBNFn(torch.autograd.Function):
         variant, K, H, E, D, alpha, n_iter, flags, check_ids = cfg
         running_mean, running_var, momentum, eps = bn_state
         qf, one, zero = _fold_train(variant, K, H, E, D, bilinear_w, query)
+        check_ids, status = check_ids if isinstance(check_ids, tuple) else (check_ids, None)
         z = arm_block_forward(ids, vals, table, qf, values, one, zero, alpha, n_iter=n_iter,
-                              write_clamped_vals=True, check_ids=check_ids, flags=flags)
+                              write_clamped_vals=True, check_ids=check_ids, flags=flags, status=status)
         y, mean, rstd, _, _ = native.bn_forward_train(z, bn_weight.detach(), bn_bias.detach(), running_mean,
                                                       running_var, momentum, eps, relu=False)
         ctx.save_for_backward(table, bilinear_w, query, values, bn_weight, ids, vals, qf, z, mean, rstd)
@@ -263,15 +266,20 @@ class HipEmbedding(nn.Module):
         super().__init__()
         self.embedding = nn.Embedding(nfeat, nemb)
         nn.init.xavier_uniform_(self.embedding.weight)
-        self.check_ids = True
+        self.check_ids = True          # True: IndexError for an out-of-range id at the NEXT call / poll() (block.IdStatus);
+        self._id_status = IdStatus()   # "sync": before the call returns (one host sync); False: unchecked
+
+    def poll(self):
+        """synchronise and raise IndexError if any call so far met an id outside [0, nfeat) (block.IdStatus)"""
+        self._id_status.poll(self.embedding.weight.device)
 
     def forward(self, x, check_ids=None):
         check = self.check_ids if check_ids is None else check_ids
         if host_ops.on_host(x["id"], x["value"], self.embedding.weight):     # never moved to the GPU: the reference's ops
             return host_ops.embedding(x["id"], x["value"], self.embedding.weight)
         if torch.is_grad_enabled() and self.embedding.weight.requires_grad:
-            return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], check)
-        return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=check)
+            return _GatherScaleFn.apply(self.embedding.weight, x["id"], x["value"], (check, self._id_status))
+        return embedding_forward(x["id"], x["value"], self.embedding.weight, check_ids=check, status=self._id_status)
 
 
 def build_mlp(ninput, nlayers, nhid, dropout, noutput=1):
@@ -326,7 +334,9 @@ class ArmNetBase(nn.Module):
             nn.init.constant_(self.ensemble_layer.weight, 0.5)
             nn.init.constant_(self.ensemble_layer.bias, 0.0)
         self._folded = ArmBlockParams()
-        self.check_ids = True          # IndexError on out-of-range ids (one host sync per call)
+        self.check_ids = True          # IndexError on out-of-range ids: True = DEFERRED to this model's next call or
+        self._id_status = self.embedding._id_status   # poll() (no host sync per forward — the reference's GPU behaviour, layers.py:20);
+                                       # "sync" = before forward returns (one host sync per call); False = unchecked
         self.n_iter = 50               # utils/entmax.py:239 default, never overridden by the reference
         self.kernel_flags = 0          # native.F_* bits for testing (faithful bisection, generic kernel)
 
@@ -365,7 +375,7 @@ class ArmNetBase(nn.Module):
             if getattr(self, "_shard", None) is not None:
                 raise NotImplementedError("training with a row-sharded table is not supported")
             cfg = (self.variant, self.nhead, self.nhid, self.nemb, self._d_k(), self.alpha, self.n_iter,
-                   self.kernel_flags, self.check_ids)
+                   self.kernel_flags, (self.check_ids, self._id_status))
             bn = self.arm_bn
             if (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
                     and vals.shape[0] * self.nemb > 1):
@@ -384,7 +394,14 @@ class ArmNetBase(nn.Module):
                                      write_clamped_vals=True, flags=self.kernel_flags, check_ids=self.check_ids)
         return arm_block_forward(ids, vals, self.embedding.embedding.weight, qf, at.values, sc, sh, self.alpha,
                                  n_iter=self.n_iter, write_clamped_vals=True, check_ids=self.check_ids,
-                                 flags=self.kernel_flags, out=out)
+                                 flags=self.kernel_flags, out=out, status=self._id_status)
+
+    def poll(self):
+        """Synchronise the device and raise IndexError if any forward of this model so far met an id outside [0, nfeat)
+        — the deferred report of `check_ids = True` (block.IdStatus; the reference's GPU path reports the same way: a
+        device-side assert at a later synchronisation, layers.py:20).  (A row-sharded table checks per call instead:
+        sharded_arm_block's all-reduced flag.)"""
+        self._id_status.poll(self.embedding.embedding.weight.device)
 
     def shard_embedding(self, group=None, release_full=False, hot_rows=0):
         """Row-shard the ARM embedding table over the process group (multi-GPU): this rank
@@ -505,8 +522,8 @@ class GraphedForward:
         self.ids = ids.clone()
         self.vals = vals.clone()
         check = model.check_ids
-        model.check_ids = False                     # no host sync inside a capture
-        try:
+        model.check_ids = bool(check)               # no host sync inside a capture: the range test stays live in the captured
+        try:                                        # kernels (block.IdStatus' pinned word), its report is read in __call__
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
@@ -523,10 +540,14 @@ class GraphedForward:
         ids, v = (x["id"], x["value"]) if vals is None else (x, vals)
         if ids.shape != self.ids.shape or v.shape != self.vals.shape:
             raise ValueError(f"graph was captured for batch shape {tuple(self.ids.shape)}, got {tuple(ids.shape)}")
+        if self.model.check_ids:
+            self.model._id_status.raise_if_set()    # an earlier replay's out-of-range id (host-memory read, no sync)
         self.ids.copy_(ids)
         self.vals.copy_(v)
         self.graph.replay()
         v.copy_(self.vals)                          # the reference's visible clamp side effect
+        if self.model.check_ids == "sync":
+            self.model.poll()
         return self.out
 
 
@@ -538,8 +559,8 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True), loss_fn, ids, vals, y)
         loss = step(ids, vals, y)          # static loss tensor, overwritten by the next call
 
-    The optimizer must be capture-safe (torch: ``capturable=True``).  Out-of-range ids are not reported inside a
-    capture (they read row 0); validate the data once outside.  x['value'] is clamped in the static copy and
+    The optimizer must be capture-safe (torch: ``capturable=True``).  An out-of-range id (it reads row 0) is reported like
+    the eager step's: IndexError at the next call or model.poll() (block.IdStatus).  x['value'] is clamped in the static copy and
     mirrored back to the caller's tensor like the eager step."""
 
     def __init__(self, model, optimizer, loss_fn, ids, vals, y, warmup=3):
@@ -548,7 +569,7 @@ class GraphedTrainStep:
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.ids, self.vals, self.y = ids.clone(), vals.clone(), y.clone()
         check = model.check_ids
-        model.check_ids = False                     # no host sync inside a capture
+        model.check_ids = bool(check)               # no host sync inside a capture (see GraphedForward)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -574,11 +595,15 @@ class GraphedTrainStep:
     def __call__(self, ids, vals, y):
         if ids.shape != self.ids.shape or vals.shape != self.vals.shape:
             raise ValueError(f"graph was captured for batch shape {tuple(self.ids.shape)}, got {tuple(ids.shape)}")
+        if self.model.check_ids:
+            self.model._id_status.raise_if_set()    # an earlier step's out-of-range id (host-memory read, no sync)
         self.ids.copy_(ids)
         self.vals.copy_(vals)
         self.y.copy_(y)
         self.graph.replay()
         vals.copy_(self.vals)
+        if self.model.check_ids == "sync":
+            self.model.poll()
         return self.loss
 
 

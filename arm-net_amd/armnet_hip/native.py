@@ -111,6 +111,8 @@ class _on:
         for t in tensors:
             if t is None:
                 continue
+            if not t.is_cuda and t.is_pinned():
+                continue        # pinned host memory is mapped into every device (block.IdStatus' deferred flag word)
             if not t.is_cuda:
                 raise ArmnetNativeError(f"expected a tensor on the HIP device, got one on {t.device} (no CPU fallback)")
             if dev is None:

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import host_ops, native
-from .block import _require_cuda
+from .block import IdStatus, _require_cuda
 from .modules import HipBatchNorm1d, HipEmbedding, _LinearSplitKFn, _MLP
 
 
@@ -52,7 +52,8 @@ class SiblingBase(nn.Module):
             self.ensemble_layer = nn.Linear(2, 1)
             nn.init.constant_(self.ensemble_layer.weight, 0.5)
             nn.init.constant_(self.ensemble_layer.bias, 0.)
-        self.check_ids = True
+        self.check_ids = True          # True: deferred IndexError (next call / poll()); "sync": per call; False: unchecked
+        self._id_status = self.embedding._id_status = IdStatus()    # one report for the model and its lookup module
         self.kernel_flags = 0
         self._fold_key = _VersionKey()
         self._folds = None
@@ -127,12 +128,20 @@ class SiblingBase(nn.Module):
         return y.squeeze(1)
 
     def _status(self, dev):
-        return torch.zeros(1, device=dev, dtype=torch.int32) if self.check_ids else None
+        """the flag word the kernels of this call write (block.IdStatus: the report is deferred to the next call / poll()
+        unless check_ids == "sync"); an earlier call's report is raised here, from host memory"""
+        if not self.check_ids:
+            return None
+        self._id_status.raise_if_set()
+        return self._id_status.word()
 
-    @staticmethod
-    def _raise_if_bad(status):
-        if status is not None and int(status.item()) != 0:
-            raise IndexError("index out of range in self")
+    def _raise_if_bad(self, status):
+        if status is not None and self.check_ids == "sync":
+            self._id_status.poll(self.embedding.embedding.weight.device)
+
+    def poll(self):
+        """synchronise and raise IndexError if any forward so far met an id outside [0, nfeat) (block.IdStatus)"""
+        self._id_status.poll(self.embedding.embedding.weight.device)
 
 
 def _bn_state(bn):
@@ -155,11 +164,13 @@ class _GcBlockFn(torch.autograd.Function):
         B, F = vals.shape
         O = K * H
         dev = vals.device
-        status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
+        check_ids, ist = check_ids
+        if check_ids:
+            ist.raise_if_set()
         native.clamp_vals(vals)
-        ex, sbuf = native.gather_map_stats(ids, vals, table.detach(), 0, status)     # exp(lookup * value) + emb_bn's batch sums
-        if status is not None and int(status.item()) != 0:
-            raise IndexError("index out of range in self")
+        ex, sbuf = native.gather_map_stats(ids, vals, table.detach(), 0, ist.word() if check_ids else None)   # exp(lookup * value) + emb_bn's batch sums
+        if check_ids == "sync":
+            ist.poll(dev)
         e_mean, e_rstd, e_scale, e_shift = native.bn_train_stats(ex, emb_w.detach(), emb_b.detach(), *emb_state, stats=sbuf)
         one, zero, sc, sh = _unit_affine(dev, O)
         qf = torch.empty(O, E, device=dev, dtype=torch.float32)
@@ -213,11 +224,13 @@ class _AfnBlockFn(torch.autograd.Function):
         O, E, flags, check_ids = cfg
         B, F = vals.shape
         dev = vals.device
-        status = torch.zeros(1, device=dev, dtype=torch.int32) if check_ids else None
+        check_ids, ist = check_ids
+        if check_ids:
+            ist.raise_if_set()
         native.clamp_vals(vals)
-        lg, sbuf = native.gather_map_stats(ids, vals, table.detach(), 1, status)     # log(lookup * value) + emb_bn's batch sums
-        if status is not None and int(status.item()) != 0:
-            raise IndexError("index out of range in self")
+        lg, sbuf = native.gather_map_stats(ids, vals, table.detach(), 1, ist.word() if check_ids else None)   # log(lookup * value) + emb_bn's batch sums
+        if check_ids == "sync":
+            ist.poll(dev)
         l_mean, l_rstd, l_scale, l_shift = native.bn_train_stats(lg, emb_w.detach(), emb_b.detach(), *emb_state, stats=sbuf)
         one, zero, _, _ = _unit_affine(dev, O)
         wc = weight.detach().contiguous()
@@ -357,7 +370,7 @@ class GC_ARMModel(SiblingBase):
         K, H, E = self.nhead, self.arm_hid, self.nemb
         at = self.attn_layers
         if self._fused_training_ok(ids, v_run):
-            cfg = (K, H, E, self.alpha, self.n_iter, self.kernel_flags, self.check_ids)
+            cfg = (K, H, E, self.alpha, self.n_iter, self.kernel_flags, (self.check_ids, self._id_status))
             w = self.embedding.embedding.weight
             out = _GcBlockFn.apply(w, at.bilinear, at.Q, at.values, self.emb_bn.weight, self.emb_bn.bias,
                                    self.arm_bn.weight, self.arm_bn.bias, ids, v_run, cfg, _bn_state(self.emb_bn),
@@ -458,7 +471,7 @@ class AFNModel(SiblingBase):
     def _afn_block_autograd(self, ids, v_run):
         """afn.py:61-69 as differentiable device ops; Dropout (afn.py:69) acts on the block's output"""
         if self._fused_training_ok(ids, v_run):
-            cfg = (self.afn_hid, self.nemb, self.kernel_flags, self.check_ids)
+            cfg = (self.afn_hid, self.nemb, self.kernel_flags, (self.check_ids, self._id_status))
             afn = _AfnBlockFn.apply(self.embedding.embedding.weight, self.afn.weight, self.afn.bias, self.emb_bn.weight,
                                     self.emb_bn.bias, self.afn_bn.weight, self.afn_bn.bias, ids, v_run, cfg,
                                     _bn_state(self.emb_bn), _bn_state(self.afn_bn))

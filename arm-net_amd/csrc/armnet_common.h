@@ -82,6 +82,16 @@ inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_s
     return c;
 }
 
+// An id outside [0, nfeat) was met: raise the caller's flag (such an id reads row 0 — memory-safe).  A relaxed SYSTEM-scope
+// store, not an atomicOr: every writer stores the same 1, and the word may live in pinned HOST memory mapped into the
+// device (the module surface's deferred check reads it on the host without touching the device: the shape of the
+// reference's GPU behaviour, where nn.Embedding's device-side assert surfaces at a later synchronisation, layers.py:20).
+#ifdef __HIPCC__
+__device__ __forceinline__ void flag_bad_id(int32_t* status) {
+    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // compute units of the current device (256 on MI355X), cached per device; 256 if the query fails
 int device_cu_count();
 

@@ -383,7 +383,7 @@ gather_map_stats_kernel(int64_t B, int F, int E, const IdT* __restrict__ ids, co
                 }
             }
         }
-        if (any_bad && id_status) atomicOr(id_status, 1);
+        if (any_bad && id_status) flag_bad_id(id_status);
         atomicAdd(&acc[f], s1);
         atomicAdd(&acc[F + f], s2);
     }

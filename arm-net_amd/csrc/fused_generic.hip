@@ -36,7 +36,7 @@ fused_generic_kernel(FusedArgs a, int S) {
             } else {
                 bool bad;
                 const uint32_t id = load_id_checked(ids + gi, a.nfeat, bad);
-                if (bad && a.id_status && e == 0) atomicOr(a.id_status, 1);
+                if (bad && a.id_status && e == 0) flag_bad_id(a.id_status);
                 row = a.table[(size_t)id * E + e];
             }
             xs[k] = row * v;

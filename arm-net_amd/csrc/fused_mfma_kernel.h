@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         const bool short_grp = gc * SPW + SPW > Bi;
         const char* vals_g = reinterpret_cast<const char*>(a.vals) + (size_t)e0 * 4;
         if constexpr (CO) {
-            if (check_ids && (raw_hi[0] != 0u || raw_lo[0] > id_max)) atomicOr(a.id_status, 1);   // lanes >= F repeat field F-1
+            if (check_ids && (raw_hi[0] != 0u || raw_lo[0] > id_max)) flag_bad_id(a.id_status);   // lanes >= F repeat field F-1
             val_cur[0] = stream_load(reinterpret_cast<const float*>(vals_g + co_off));   // distributed at staging time
             const int idc = (int)(min(raw_lo[0], id_max) & id_mask);                   // memory-safe even when unchecked
 #pragma unroll
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 bool bad = false;
 #pragma unroll
                 for (int n = 0; n < NI; ++n) bad |= !pad[n] && (raw_hi[n] != 0u || raw_lo[n] > id_max);
-                if (bad && chunk == 0) atomicOr(a.id_status, 1);
+                if (bad && chunk == 0) flag_bad_id(a.id_status);
             }
         }
         auto body = [&](auto is_short) {                             // two copies: the common one has no per-lane select

@@ -37,7 +37,7 @@ route_count_kernel(int64_t n, const IdT* __restrict__ ids, int R, int64_t nfeat,
         if (i < n) {
             int owner, local; bool bad;
             owner_of(ids, i, R, nfeat, owner, local, bad);
-            if (bad && id_status) atomicOr(id_status, 1);
+            if (bad && id_status) flag_bad_id(id_status);
             atomicAdd(&hist[owner], 1);
         }
     }

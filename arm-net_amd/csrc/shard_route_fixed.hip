@@ -69,7 +69,7 @@ template <typename IdT>
 __device__ __forceinline__ uint32_t checked_id(const IdT* ids, int64_t i, int64_t nfeat, int32_t* id_status) {
     const uint64_t v = (uint64_t)(int64_t)ids[i];
     const bool bad = v >= (uint64_t)nfeat;
-    if (bad && id_status) atomicOr(id_status, 1);
+    if (bad && id_status) flag_bad_id(id_status);
     return bad ? 0u : (uint32_t)v;
 }
 

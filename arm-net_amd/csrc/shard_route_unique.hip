@@ -19,7 +19,7 @@ __global__ void uniq_mark_kernel(int64_t n, const IdT* __restrict__ ids, int R, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t v = (uint64_t)(int64_t)ids[i];
         const bool bad = v >= (uint64_t)nfeat;
-        if (bad && id_status) atomicOr(id_status, 1);
+        if (bad && id_status) flag_bad_id(id_status);
         const uint32_t id = bad ? 0u : (uint32_t)v;
         mark[(int64_t)(id % (uint32_t)R) * L + id / (uint32_t)R] = 1;
     }

@@ -107,7 +107,7 @@ __global__ void gather_scale_kernel(int64_t n_rows, int E, const IdT* __restrict
         const int c = (int)(i - r * cpr);
         bool bad;
         const uint32_t id = load_id_checked(ids + r, nfeat, bad);
-        if (bad && id_status) atomicOr(id_status, 1);
+        if (bad && id_status) flag_bad_id(id_status);
         const float v = vals ? vals[r] : 1.0f;
         const float* src = table + (size_t)id * E + c * VEC;
         float* dst = out + r * E + c * VEC;

@@ -114,7 +114,10 @@ def build_model(a, device, rank=0, world=1, regime=None):
             m.arm_bn.running_mean.copy_(torch.rand(m.arm_bn.running_mean.shape, generator=g) + 0.5)
             m.arm_bn.running_var.copy_(torch.rand(m.arm_bn.running_var.shape, generator=g) * 1.5 + 0.5)
     m.eval()
-    m.check_ids = False                         # no host sync inside the timed region
+    # round 6: the default product path is what is timed — the in-kernel id range test is LIVE and its report deferred
+    # (block.IdStatus: a pinned host word, no host sync per step).  The row-sharded step's check is an all-reduce + host
+    # sync per call (every rank must raise together): off there, as in a serving loop that polls per N steps.
+    m.check_ids = a.shard != "rows"
     m = m.to(device)
     if a.shard == "rows":
         from armnet_hip.sharded import RowShardedTable
@@ -757,8 +760,22 @@ def main():
     # ... and three more at the very end: most of the windows lie late in the life of the process, when a freshly leased
     # device has long finished whatever it does in its first seconds
     stuck = (a.shard == "both" and not sharded["done"]) or (big["err"] and not big["done"])   # a collective never returned
+    unchecked_ms = None
+    if not stuck and a.shard != "rows":
+        # the same step WITHOUT the in-kernel id range test (what rounds 1-5 timed as `value`), beside the checked `value`
+        models[head].check_ids = False
+        settle_clocks(head_step[0], min(a.settle_ms, 30.0), cap_ms=200.0)
+        unchecked_ms = median([w[0] for w in windows(head_step[0], 3)])
+        models[head].check_ids = True
     for i in range(0 if stuck else 3):
         head_window("end of run" if i == 0 else "previous window")
+    ids_ok = None
+    if not stuck and a.shard != "rows":
+        try:
+            models[head].poll()                           # the deferred report of every step this process ran
+            ids_ok = True
+        except IndexError:
+            ids_ok = False
     head_windows_red = res_provisional if stuck else reduce_results()
     live_ceiling = [None]
     if rank == 0 and world == 1 and a.shard == "replicate":
@@ -853,7 +870,9 @@ def main():
                                    f"(ids+vals+out = {ws_mb:.0f} MB per rotation > 256 MiB Infinity Cache; only "
                                    f"the {a.nfeat * a.nemb * 4 / 1e6:.0f} MB table is re-read); every step of a window gets a "
                                    f"pristine (unclamped) copy of its values from a pool of {POOL} buffers restored before the "
-                                   f"window, so the in-place clamp's write-back is live in the timed steps"
+                                   f"window, so the in-place clamp's write-back is live in the timed steps; the in-kernel id range "
+                                   f"test is live (the module's default check_ids: report deferred to the next call / poll(), no "
+                                   f"host sync per step)"
                                    + ("" if a.warmup + a.steps <= POOL else f" (first {POOL} steps of a window only)")
                                    + ("; no clock-settling pre-run; " if a.settle_ms <= 0 else
                                       f"; device clocks settled to a plateau by >= {a.settle_ms:g} ms of the same step, untimed; "
@@ -874,6 +893,14 @@ def main():
                                      + (" + DNN ensemble branch (second table lookup, deep MLP 2x256 on the HIP head, "
                                         "ensemble Linear)" if a.ensemble else "")},
         }
+        if unchecked_ms is not None:
+            line["id_check"] = {"in_value": True, "all_ids_in_range_at_poll": ids_ok,
+                                "unchecked": {"value": world * a.batch * a.steps / (unchecked_ms * 1e-3), "unit": "samples/s",
+                                              "ms_per_step": unchecked_ms / a.steps},
+                                "note": "`value` runs the module's default path: armnet_fused_fwd_f32 with the id range test on, "
+                                        "its flag a pinned host word read at the next call / model.poll() (the reference's GPU "
+                                        "behaviour: an asynchronous device-side assert, layers.py:20); `unchecked` = "
+                                        "check_ids = False, what rounds 1-5 timed"}
         if other_alphas:
             line["other_alphas"] = dict(other_alphas, note="the same fused block, batches and timing loop with alpha = 1.7 (the "
                                         "reference's argparse default, train.py:33) and 1.5; `value` stays alpha = "

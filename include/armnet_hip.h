@@ -102,8 +102,12 @@ int armnet_fold_params_f32(int variant, int K, int H, int E, int D,
  * table: [nfeat,E]; values: [O,F].  n_iter is the reference's bisection count (default 50): with
  * n_iter >= 24 and alpha <= 2 a converged Newton/Michelot solve of the same root is used unless
  * ARMNET_F_FAITHFUL_BISECT is set.
- * id_status: optional device int32; bit 0 is OR-ed in when any id is outside [0,nfeat)
- * (such ids read row 0 instead of faulting).  The host wrapper turns it into IndexError.
+ * id_status: optional int32 the DEVICE can write — device memory, or (round 6) pinned host memory mapped into the
+ * device: 1 is stored (relaxed, system scope; never cleared by the library) when any id is outside [0,nfeat); such ids
+ * read row 0 instead of faulting.  The host wrapper turns it into IndexError — by default at its NEXT call or at its
+ * poll(), not with a synchronisation behind every launch: the reference's nn.Embedding on a GPU (layers.py:20) reports a
+ * bad id by an asynchronous device-side assert, and train.py:117-121 never synchronises for it.  The same holds for every
+ * id_status argument below.
  */
 int armnet_fused_fwd_f32(int64_t B, int F, int E, int O, float alpha, int n_iter, uint32_t flags,
                          const void* ids, int id_type, float* vals,

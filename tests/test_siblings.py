@@ -338,9 +338,11 @@ def test_sibling_fused_step_with_frozen_parameters(kind):
             tracked = int(m.emb_bn.num_batches_tracked)
             bad = ids.clone()
             bad[3, 2] = nfeat
+            m.check_ids = "sync"                           # raise inside the call, before any statistic is touched
             with pytest.raises(IndexError):
                 m({"id": bad, "value": vals.clone()})
             assert int(m.emb_bn.num_batches_tracked) == tracked
+            m.check_ids = True
     gmax = max(float(g_.abs().max()) for g_ in grads[0].values() if g_ is not None)
     for k, gfree in grads[1].items():
         if gfree is not None and float(grads[0][k].abs().max()) >= 1e-5 * gmax:     # (analytically zero ones: rounding noise)
@@ -523,8 +525,14 @@ def test_out_of_range_id_raises_indexerror_for_the_siblings():
         m = _build(meta, sd, DEV)
         bad = ids.copy()
         bad[2, 5] = meta["ctor"]["nfeat"]
+        x = {"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+        with torch.no_grad():
+            m(x)                                           # round 6: the report is deferred (block.IdStatus) ...
+        with pytest.raises(IndexError):
+            m.poll()                                       # ... to poll() or the next call
+        m.check_ids = "sync"
         with pytest.raises(IndexError), torch.no_grad():
-            m({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
+            m(x)
 
 
 def _grid_model(variant, F, E, K, nhid, alpha, seed):
