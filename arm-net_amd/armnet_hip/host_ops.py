@@ -19,6 +19,22 @@ def on_host(*tensors):
     return all(not t.is_cuda for t in tensors)
 
 
+def note_host_branch(owner):
+    """A model that was never moved to the GPU runs the reference's ATen chain on the host — the reference's own device
+    semantics (model_utils.py:86), but orders of magnitude slower than the HIP path.  On a box that HAS a GPU that is most
+    likely a forgotten `.cuda()`: say so once per model (round-5 advisor finding; `model.allow_host = True` or
+    ARMNET_ALLOW_HOST=1 silences it).  On a box without a GPU there is nothing to warn about."""
+    if getattr(owner, "_host_noted", False) or getattr(owner, "allow_host", False):
+        return
+    owner._host_noted = True
+    import os
+    if torch.cuda.is_available() and not os.environ.get("ARMNET_ALLOW_HOST"):
+        import warnings
+        warnings.warn(f"{type(owner).__name__}: model and batch are in host memory — running the reference's ATen op chain on "
+                      "the CPU, not the HIP kernels (this box has a GPU: call model.cuda() and move the batch, or set "
+                      "model.allow_host = True to silence this)", RuntimeWarning, stacklevel=3)
+
+
 def clamp_vals_(vals):
     """armnet_1h.py:81 / armnet.py:82: x['value'].clamp_(0.001, 1.) in place"""
     return vals.clamp_(0.001, 1.0)

@@ -359,6 +359,7 @@ class ArmNetBase(nn.Module):
         at = self.attn_layer
         bw = at.bilinear_w.weight if self.variant == native.ONE_HEAD else at.bilinear_w
         if host_ops.on_host(ids, vals, self.embedding.embedding.weight) and getattr(self, "_shard", None) is None:
+            host_ops.note_host_branch(self)
             z = host_ops.arm_block(self.variant == native.ONE_HEAD, ids, vals, self.embedding.embedding.weight, bw,
                                    at.query, at.values, self.alpha, n_iter=self.n_iter)
             y = self.arm_bn(z)

@@ -306,7 +306,7 @@ class RowShardedTable:
                           RuntimeWarning, stacklevel=3)
         if self.slot_lookups is None:
             self._slot_auto = True
-            m = max(int(n), 1)
+            m = max(int(n), 1, getattr(self, "_slot_floor", 0))
             if dist.is_initialized() and self.world > 1:
                 dev = self._table_local.device
                 t = torch.tensor([m], dtype=torch.int64, device="cpu" if self._via_host or not dev.type == "cuda" else dev)
@@ -318,7 +318,8 @@ class RowShardedTable:
     def _cold_lookups(self, flat):
         """lookups of this step that the exchanges have to carry with hot rows replicated: n x the cold fraction, which is
         MEASURED on the first lookup (one host read, where the step size is agreed anyway) and kept; later steps are
-        assumed to be drawn from the same distribution — a colder one overflows a slot and is repaired like any overflow"""
+        assumed to be drawn from the same distribution — a colder one overflows a slot; the poll() that sees the overflow drops
+        the fraction (and the agreed cold step size) on every rank, and the next lookup measures them again"""
         n = flat.numel()
         if getattr(self, "_cold_frac", None) is None or self.slot_lookups is None:
             cold = int((flat >= self.hot_rows).sum().item()) if n else 0
@@ -376,6 +377,14 @@ class RowShardedTable:
             self._overflow.zero_()
         if bool(h[0].item()):
             self.slot_distinct = None                  # a slot overflowed somewhere: every rank re-measures at its next lookup
+            if self.hot_rows:
+                # ... and so is the cold fraction that sizes the slots beside the hot rows (round-5 advisor finding: it was
+                # measured once, so a stream that turned colder overflowed on every later step); the agreed step size is
+                # re-agreed with it (MAX over the ranks, never below the old one) when it was measured and not set
+                self._cold_frac = None
+                if getattr(self, "_slot_auto", False) and self.slot_lookups is not None:
+                    self._slot_floor = max(getattr(self, "_slot_floor", 0), int(self.slot_lookups))
+                    self.slot_lookups = None
         if getattr(self, "_slot_auto", False) and self.slot_lookups is not None and int(h[2].item()) > self.slot_lookups:
             self.slot_lookups = int(h[2].item())   # a larger step than the agreed one was seen somewhere: same value on every rank
         return bool(h[0].item()), bool(h[1].item())
@@ -432,25 +441,33 @@ class RowShardedTable:
                                                           perm_with_gather=True, **hot)
             else:
                 send_pad, perm_pad = self.ops.route_fixed(flat, R, self.nfeat, cap, dedup, self._overflow, id_status, **hot)
+        elif n == 0:
+            # an empty slice (a ragged rank, the empty last micro-batch) still takes part in the exchanges — with or without
+            # hot rows (round-5 advisor finding: with hot_rows > 0 this used to fall into the raise below on ONE rank while
+            # its peers blocked in all_to_all_single): filler requests for local row 0, nothing to permute
+            send_pad = torch.zeros(R * cap, device=dev, dtype=torch.int32)
+            perm_pad = torch.empty(0, device=dev, dtype=torch.int32)
         elif N:
             raise native.ArmnetNativeError("hot_rows needs the fused fixed-protocol route: fused_route = True, an ops object with "
                                            "route_fixed, and positions that fit 32 bits (R * cap + hot_rows < 2^31, "
                                            "nfeat < 2^32)")
         else:
-            if n == 0:                                     # an empty slice still takes part in the exchanges
-                counts = torch.zeros(R, device=dev, dtype=torch.int32)
-                send_local = torch.zeros(1, device=dev, dtype=torch.int32)
-                perm = torch.empty(0, device=dev, dtype=torch.int32)
-            elif id_status is not None:
+            if id_status is not None:
                 counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup, id_status=id_status)
             else:
                 counts, send_local, perm = self.ops.route(flat, R, self.nfeat, dedup=dedup)
             send_pad, perm_pad = self.ops.pad_route(counts, send_local, perm, R, cap, self._overflow)
         E = self.table_local.shape[1]
         pending = getattr(perm_pad, "_armnet_pending", None)
-        gather = (lambda idx, out=None: self.ops.gather_perm(idx, self.table_local, pending, out=out)) if pending is not None \
-            else (lambda idx, out=None: self.ops.gather(idx, self.table_local, out=out) if out is not None
-                  else self.ops.gather(idx, self.table_local))
+        def gather(idx, out=None):
+            if pending is not None:
+                return self.ops.gather_perm(idx, self.table_local, pending, out=out)
+            if out is not None:
+                try:
+                    return self.ops.gather(idx, self.table_local, out=out)
+                except TypeError:                      # an ops object whose gather has no `out`: the caller copies
+                    pass
+            return self.ops.gather(idx, self.table_local)
         if pending is not None:
             del perm_pad._armnet_pending
         # the buffer the fused block reads: R * cap received rows, then (hot_rows > 0) the replicated hot rows

@@ -101,7 +101,10 @@ class SiblingBase(nn.Module):
     def _on_host(self, ids, v):
         """a model that was never moved to the GPU, called with host tensors: the reference's ATen op chain from this
         module's own sub-modules (host_ops.py; the reference dispatches the same way, model_utils.py:86)"""
-        return host_ops.on_host(ids, v, self.embedding.embedding.weight)
+        host = host_ops.on_host(ids, v, self.embedding.embedding.weight)
+        if host:
+            host_ops.note_host_branch(self)
+        return host
 
     def _needs_autograd(self):
         """training mode, or eval mode with autograd on and a trainable parameter: the composed differentiable path"""

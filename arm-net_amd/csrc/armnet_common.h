@@ -64,7 +64,7 @@ inline SparseMapCfg make_sparse_cfg(float alpha, int n_iter, int d, int ensure_s
     // 6e-7 / 2e-7 (the class of kNewtonTol / tau_tol): alpha = 1.7 -> 1.0e-4, 1.3 -> 2.3e-4, 1.1 -> 6.7e-5, 1.9 -> 7e-6.
     // alpha = 1.5 recomputes (t - d)^2 exactly; only the unverified residual f'' d^2 / 2 <= nfield d^2 is left: 4e-7.
     c.lin_tol = 0.f;
-    if (alpha > 1.0f && alpha < 2.0f) {
+    if (alpha > 1.0f && alpha < 2.0f && !(flags & ARMNET_F_NO_LIN_FINISH)) {
         if (alpha == 1.5f) c.lin_tol = sqrtf(4e-7f / (float)(d > 0 ? d : 1));
         else c.lin_tol = fminf(powf(2e-6f, c.am1), sqrtf(4e-7f / (c.r * (c.r - 1.0f))));
     }

@@ -431,6 +431,9 @@ __device__ __forceinline__ bool mlp_body(const MlpArgs& a) {
 
     // stage q of the weight stream -> ring slot q % kWRing: NT*P lane-linear 1-KiB blocks, NW per wave
     auto issue_w = [&](int q) {
+#ifdef ARMNET_MLP_NOW              // developer ablation (compile-time, results are garbage): no weight LDS-DMA
+        return;
+#endif
         const uint8_t* src = q < KS1 ? w1 + (int64_t)q * ST1 : w2 + (int64_t)(q - KS1) * ST2;
         uint8_t* dst = lds + (q % kWRing) * ST1;
 #pragma unroll
@@ -453,6 +456,9 @@ __device__ __forceinline__ bool mlp_body(const MlpArgs& a) {
         xsrc[j] = a.x + rg * a.ldx + 4 * ((lane & 3) ^ ((r >> 2) & 3));
     }
     auto issue_x = [&](int s) {
+#ifdef ARMNET_MLP_NOX              // developer ablation (compile-time, results are garbage): no activation LDS-DMA
+        return;
+#endif
         uint8_t* dst = xring + (s % kXRing) * 2048;
 #pragma unroll
         for (int j = 0; j < 2; ++j)

@@ -67,6 +67,9 @@ typedef enum armnet_variant {
                                             * arithmetic is fp32 on this device.  Held to the reference's vectors at <= 2e-6
                                             * (alpha <= 2) / 2e-5 (alpha > 2) by tests/test_hip_parity.py */
 #define ARMNET_F_FORCE_GENERIC      0x4u /* bypass the MFMA-specialised kernel (testing) */
+#define ARMNET_F_NO_LIN_FINISH      0x8u /* 1 < alpha < 2 on the matrix-core kernel: every Newton step is confirmed by an
+                                            evaluation (no first-order finish of a tiny last step; rounds 1-4 behaviour) —
+                                            a run-time switch for bisecting a regression without a rebuild */
 
 int armnet_abi_version(void);
 const char* armnet_strerror(int status);

@@ -872,3 +872,58 @@ def test_run_sh_500_wide_heads_take_the_hip_head_kernel(name):
         y_blas = m({"id": x["id"], "value": torch.from_numpy(vals.copy()).to(DEV)}).cpu().numpy()
     assert _rel_err(y, ref["logits"]) <= TOL
     assert _rel_err(y, y_blas) <= TOL
+
+
+@pytest.mark.parametrize("alpha", [1.3, 1.5, 1.7])
+@pytest.mark.parametrize("F,spread", [(39, 0.0), (39, 3e-4), (39, 3e-2), (48, 1e-3), (10, 1e-3)])
+def test_first_order_newton_finish_on_near_tied_gate_rows(alpha, F, spread):
+    """round-5 advisor finding (low): the first-order finish of the Newton solver (1 < alpha < 2: a step below `lin_tol` is
+    taken without a confirming evaluation, p follows as p - r t^(r-1) step, clamped at 0) was only exercised by the fixtures'
+    ordinary rows.  Adversarial rows here: every field of a sample looks up (nearly) the SAME embedding, so a row's gates are
+    tied to within `spread` x their scale — many elements enter or leave the support within one step — at widths up to the
+    kernel's 48 fields, with larger and smaller gate scales per neuron.  The block output is held to the oracle's literal
+    bisection at the usual bar, with the finish on AND switched off at run time (ARMNET_F_NO_LIN_FINISH)."""
+    from armnet_hip import native
+    from models.armnet_1h import ARMNetModel
+    torch.manual_seed(int(alpha * 10) + F)
+    E, H, nfeat, B = 16, 32, 64, 203
+    m = ARMNetModel(F, nfeat, E, alpha, H, E, 1, 16, 0.0, False, 1, 16)
+    g = torch.Generator().manual_seed(F)
+    with torch.no_grad():
+        base = torch.randn(1, E, generator=g) * 0.5
+        m.embedding.embedding.weight.copy_(base + spread * torch.randn(nfeat, E, generator=g))
+        m.attn_layer.query.mul_(torch.logspace(-1, 1.2, H).unsqueeze(1))          # gate scale 0.1 ... 16 over the neurons
+        m.arm_bn.running_mean.uniform_(0.5, 1.5, generator=g)
+        m.arm_bn.running_var.uniform_(0.5, 2.0, generator=g)
+    m = m.eval().to(DEV)
+    ids = torch.randint(0, nfeat, (B, F), generator=g)
+    vals = 1.0 - 1e-3 * torch.rand(B, F, generator=g)                              # values ~ 1: the ties survive the scaling
+    vals[::7] = torch.rand(F, generator=g)                                          # ... and some ordinary rows
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = orc.arm_block("1h", ids.numpy(), vals.numpy().copy(), sd, alpha)
+    outs = {}
+    for name, fl in (("lin", 0), ("no_lin", native.F_NO_LIN_FINISH)):
+        m.kernel_flags = fl
+        with torch.no_grad():
+            outs[name] = m.arm_block(ids.to(DEV), vals.clone().to(DEV)).cpu().numpy()
+        e = _rel_err(outs[name], want)
+        print(f"alpha={alpha} F={F} spread={spread:g} {name}: {e:.2e}")
+        assert e <= TOL, (name, e)
+    assert np.isfinite(outs["lin"]).all()
+
+
+def test_host_branch_warns_once_on_a_box_with_a_gpu():
+    """round-5 advisor finding (low): a model that was never moved to the GPU runs the reference's ATen chain on the host —
+    the reference's own device semantics, but on a GPU box most likely a forgotten .cuda(): one RuntimeWarning per model"""
+    import warnings
+    from models.armnet_1h import ARMNetModel
+    m = ARMNetModel(10, 50, 8, 1.7, 4, 8, 1, 8, 0.0, False, 1, 8).eval()
+    x = {"id": torch.randint(0, 50, (5, 10)), "value": torch.rand(5, 10)}
+    with pytest.warns(RuntimeWarning, match="host memory"), torch.no_grad():
+        m(x)
+    with warnings.catch_warnings(), torch.no_grad():
+        warnings.simplefilter("error")
+        m(x)                                                                        # once
+        m2 = ARMNetModel(10, 50, 8, 1.7, 4, 8, 1, 8, 0.0, False, 1, 8).eval()
+        m2.allow_host = True
+        m2(x)

@@ -447,6 +447,65 @@ def test_hot_rows_on_one_rank_without_a_process_group():
         RowShardedTable(table, nfeat, None, ops=NumpyShardOps(), hot_rows=nfeat + 1)
 
 
+def test_empty_slice_with_hot_rows_joins_the_exchanges_and_a_colder_stream_relearns_its_slots():
+    """round-5 advisor findings (medium x 2), one rank with the numpy double.  (1) hot_rows > 0 and an EMPTY lookup (a ragged
+    rank, the empty last micro-batch): used to raise on that rank alone while its peers blocked in all_to_all_single; it now
+    sends filler requests and returns the hot rows behind an empty permutation.  (2) The cold fraction that sizes the slots
+    beside the hot rows was measured once: a stream that turned colder overflowed on EVERY later step (poll() re-learned the
+    distinct count only).  The poll() that sees the overflow now drops the fraction and the agreed cold step size; the next
+    lookup measures both again, so the step after the repair fits."""
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    from armnet_hip.sharded import RowShardedTable
+    nfeat, E, N = 5003, 4, 512
+    table = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(1))
+    ids = _zipf_ids(nfeat, (50, 7), 3)
+    for dedup in (False, True):
+        shard = RowShardedTable(table.clone(), nfeat, None, ops=NumpyShardOps(), dedup=dedup, hot_rows=N)
+        shard.whole_shard = False
+        rows, perm = shard.lookup(ids)                                             # sizes the slots
+        rows0, perm0 = shard.lookup(ids[:0])                                       # (1)
+        assert perm0.numel() == 0 and torch.equal(rows0[-N:], table[:N]) and rows0.shape[0] == rows.shape[0]
+        assert not shard.overflowed()
+    # (2): first step all hot -> cold fraction 0, slots of one lookup; then a cold stream
+    shard = RowShardedTable(table.clone(), nfeat, None, ops=NumpyShardOps(), dedup=False, hot_rows=N)
+    shard.whole_shard = False
+    hot_ids = torch.randint(0, N, (50, 7), generator=torch.Generator().manual_seed(5))
+    rows, perm = shard.lookup(hot_ids)
+    assert torch.equal(rows[perm.long()].view(50, 7, E), table[hot_ids]) and not shard.overflowed()
+    small = rows.shape[0] - N
+    cold_ids = torch.randint(N, nfeat, (50, 7), generator=torch.Generator().manual_seed(6))
+    shard.lookup(cold_ids)
+    assert shard.overflowed()                                                      # flagged, sizes dropped
+    overflows = 0
+    for seed in range(7, 11):                                                      # four more cold steps: they fit now
+        ids2 = torch.randint(N, nfeat, (50, 7), generator=torch.Generator().manual_seed(seed))
+        rows2, perm2 = shard.lookup(ids2)
+        if shard.overflowed():
+            overflows += 1
+        else:
+            assert torch.equal(rows2[perm2.long()].view(50, 7, E), table[ids2])
+    assert overflows == 0 and rows2.shape[0] - N > 10 * small
+
+
+def test_ops_object_without_out_support_on_the_one_rank_hot_row_path():
+    """round-5 advisor finding (low): an ops object whose gather() has no `out` parameter used to raise TypeError before the
+    documented fallback copy was reached"""
+    sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
+    from armnet_hip.sharded import RowShardedTable
+
+    class NoOut(NumpyShardOps):
+        def gather(self, idx, table):
+            return NumpyShardOps.gather(self, idx, table)
+
+    nfeat, E = 3001, 4
+    table = torch.randn(nfeat, E, generator=torch.Generator().manual_seed(2))
+    ids = _zipf_ids(nfeat, (40, 5), 9)
+    shard = RowShardedTable(table.clone(), nfeat, None, ops=NoOut(), dedup=False, hot_rows=256)
+    shard.whole_shard = False
+    rows, perm = shard.lookup(ids)
+    assert torch.equal(rows[perm.long()].view(40, 5, E), table[ids])
+
+
 def test_slot_capacity_clamps_only_to_a_true_upper_bound():
     sys.path.insert(0, os.path.join(ROOT, "arm-net_amd"))
     from armnet_hip.sharded import fixed_ingress_bytes, slot_capacity
