@@ -360,6 +360,19 @@ def live_pattern_ceiling(a):
         return None
 
 
+ERROR_RC = {"launch_timeout": 3, "init": 4, "device": 5, "deadline": 6, "ranks": 7}
+
+
+def error_line(a, what, msg, world=None):
+    """the ONE stdout line of a run that could not produce a number (round-5 verdict, next 5c: an RCCL failure must be a
+    line with "error" and a non-zero exit code, not a hang): the contract's keys with value = null"""
+    return {"metric": "samples/sec, ARM-Net forward (fused embedding + ARM interaction block), Criteo nfield=39 nemb=16 B=65536",
+            "value": None, "unit": "samples/s", "n_gpus": int(world if world is not None else a.gpus), "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": {"workload": "not measured"},
+            "error": f"{what}: {msg}", "error_kind": what, "rc": ERROR_RC[what]}
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when the first communicator
@@ -367,18 +380,41 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    def fail(what, msg, world=None, print_line=True):
+        """leave with the error line (rank 0 / the launcher only: the line is ONE) and the kind's exit code, without
+        tearing a possibly wedged process group down"""
+        sys.stderr.write(f"bench.py: {what}: {msg}\n")
+        if print_line:
+            os.write(json_fd, (json.dumps(error_line(a, what, msg, world)) + "\n").encode())
+        os._exit(ERROR_RC[what])
+
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU over RCCL), exactly the
-        # command the driver would use; rank 0 of the child job prints the JSON line on the inherited stdout
+        # command the driver would use; rank 0 of the child job prints the JSON line on the inherited stdout.  Under a
+        # deadline: a child job that wedges (an RCCL collective that never returns takes its watchdogs' os._exit paths,
+        # but a rank stuck INSIDE the runtime may not) is killed as a process group and reported as an error line.
+        import signal
         import socket
         import subprocess
-        os.dup2(json_fd, 1)
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        limit = float(os.environ.get("ARMNET_BENCH_LAUNCH_TIMEOUT", "1800"))
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, start_new_session=True)
+        try:
+            out, _ = child.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)
+            child.wait()
+            fail("launch_timeout", f"the {a.gpus}-rank job did not finish within {limit:g} s and was killed")
+        lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+        if lines:
+            os.write(json_fd, (lines[-1] + "\n").encode())
+            sys.exit(child.returncode)
+        fail("ranks", f"the {a.gpus}-rank job exited with code {child.returncode} without printing a line (see stderr)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.shard is None:
         a.shard = "both" if world > 1 else "replicate"
@@ -390,14 +426,40 @@ def main():
     backend = os.environ.get("ARMNET_BENCH_BACKEND", "nccl")
     if "ARMNET_BENCH_DEVICE" in os.environ:
         local = int(os.environ["ARMNET_BENCH_DEVICE"])
+    if world != a.gpus:
+        fail("ranks", f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", print_line=rank == 0)
+    # the whole run under a deadline (N > 1): whatever wedges — a barrier of the replicated windows, a collective outside
+    # the watched row-sharded sections — ends as an error line and a non-zero exit code instead of a hang
     if use_dist:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        import threading
+        deadline = float(os.environ.get("ARMNET_BENCH_DEADLINE", "1500"))
+        dl = threading.Timer(deadline, lambda: fail("deadline", f"rank {rank}: the run did not finish within {deadline:g} s "
+                                                               "(a collective that never returned?)", world, rank == 0))
+        dl.daemon = True
+        dl.start()
+    try:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        torch.zeros(1, device=dev)
+    except Exception as e:  # noqa: BLE001
+        fail("device", f"rank {rank}: cuda:{local} is not usable: {type(e).__name__}: {e}", world, rank == 0)
+    ranks_seen = 1
+    if use_dist:
+        import datetime
+        try:
+            tmo = datetime.timedelta(seconds=float(os.environ.get("ARMNET_BENCH_INIT_TIMEOUT", "300")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+            # the first collective (RCCL builds its communicator here): how many ranks are really in the job
+            t = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(t)
+            ranks_seen = int(t.item())
+        except Exception as e:  # noqa: BLE001
+            fail("init", f"rank {rank}: {backend} process group over {world} ranks: {type(e).__name__}: {e}", world, rank == 0)
+        if ranks_seen != world:
+            fail("ranks", f"the first all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}", world, rank == 0)
     O = a.nhead * a.nhid
     NB = max(1, a.rotate)
 
@@ -598,6 +660,27 @@ def main():
                         raise
                     mode["in_flight_err"] = f"in_flight={nfl}: {type(e).__name__}: {e}"
             mode["exchange"] = getattr(sh, "last_path", None)
+            # the lookup half of the step ALONE on one stream — routing, both exchanges, the owner-side gather — so that the
+            # curve explains itself: step time against (this + the kernel's time with the table local)
+            try:
+                lt = [0]
+
+                def lookup_only():
+                    k = lt[0] % NB
+                    lt[0] += 1
+                    with torch.no_grad():
+                        return sh.lookup(batches[k][0])
+
+                for _ in range(a.warmup):
+                    lookup_only()
+                ms_l, _ = timed(lookup_only, a.steps, sync_all)
+                tl = torch.tensor([ms_l], device=dev, dtype=torch.float64)
+                if use_dist:
+                    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+                sh.overflowed()                              # (resets the flag; these steps' rows were not used)
+                mode["lookup_ms"] = float(tl.item())
+            except Exception as e:  # noqa: BLE001
+                mode["lookup_err"] = f"{type(e).__name__}: {e}"
             best = min(mode["by_in_flight"], key=mode["by_in_flight"].get)
             mode["ms"], mode["in_flight"] = mode["by_in_flight"][best], int(best)
             # bytes one rank RECEIVES from the other ranks per step, and what that means per xGMI link (R - 1 peers, one
@@ -920,6 +1003,9 @@ def main():
                 "note": f"the same {a.steps} steps enqueued on {a.in_flight} alternating streams: consecutive launches "
                         f"overlap (launch gap, block prologue and tail hidden); `value`, `roofline` and `regimes` are the "
                         f"one-stream numbers"}
+        if use_dist:
+            line["rccl_ranks_seen"] = ranks_seen
+            line["backend"] = backend
         if a.shard == "both":
             line["replicated"] = {"value": replicated_value, "unit": "samples/s", "ms_per_step": replicated_ms,
                                   "note": "table on every rank, batch split, no data-path collective",
@@ -934,8 +1020,15 @@ def main():
                      "samples_per_s_by_steps_in_flight": {k: world * a.batch * a.steps / (v * 1e-3)
                                                           for k, v in m_["by_in_flight"].items()},
                      "ingress_bytes_per_rank_per_step": m_["ingress_bytes_per_rank_per_step"],
-                     "implied_gb_per_s_per_link": m_.get("implied_gb_per_s_per_link")}
-                for k in ("slot_rows", "overflow", "in_flight_err"):
+                     "ingress_bytes_per_rank": m_["ingress_bytes_per_rank_per_step"],
+                     "implied_gb_per_s_per_link": m_.get("implied_gb_per_s_per_link"),
+                     # the halves of a step, each measured alone: routing + both exchanges + owner gather | the fused kernel
+                     # with the table local (the replicated step's HIP-event time)
+                     "exchange_ms": (m_["lookup_ms"] / a.steps) if m_.get("lookup_ms") else None,
+                     "kernel_ms": ev_ms / a.steps}
+                if o["exchange_ms"] and world > 1:
+                    o["exchange_gb_per_s_per_link"] = (m_["ingress_bytes_per_rank_per_step"] / (world - 1)) / (o["exchange_ms"] * 1e-3) / 1e9
+                for k in ("slot_rows", "overflow", "in_flight_err", "lookup_err"):
                     if m_.get(k) is not None:
                         o[k] = m_[k]
                 return o
@@ -956,7 +1049,9 @@ def main():
                         f"{a.nfeat} rows per rank): the owners ship their shards as they are — one all_gather_into_tensor "
                         f"of {a.nfeat * a.nemb * 4 / 1e6:.0f} MB per rank and step into a transient buffer, direct row "
                         f"addresses — instead of answering request lists.  ingress_bytes_per_rank_per_step = what one rank "
-                        f"receives from its {world - 1} peers; implied_gb_per_s_per_link = that per peer / step time.  "
+                        f"receives from its {world - 1} peers; implied_gb_per_s_per_link = that per peer / step time; exchange_ms = "
+                        f"the lookup half of a step alone (routing, both exchanges, owner-side gather), kernel_ms = the fused "
+                        f"kernel with the table local, exchange_gb_per_s_per_link = the ingress per peer / exchange_ms.  "
                         f"steps_in_flight > 1: consecutive steps alternate between that many streams, so the row exchange "
                         f"of one step runs under the fused kernel of the previous one"}
         if big["done"] or big["err"]:

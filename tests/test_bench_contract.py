@@ -137,9 +137,13 @@ def _check_two_rank_line(d):
     assert set(by) == {"whole_shards", "fixed"} and rs["exchange"] in by and rs["ids"] == "uniform"
     assert rs["value"] == by["fixed"]["value"] and rs["exchange"] == "fixed"   # the protocol north_star names, not the faster
     assert len(rep["value_windows_ms"]) >= 4 and "value_windows_ms" not in d   # the windows are the replicated step's
+    assert d["rccl_ranks_seen"] == 2 and d["backend"] in ("nccl", "gloo")
     for v in by.values():
         assert set(v["samples_per_s_by_steps_in_flight"]) == {"1", "2"}
         assert v["ingress_bytes_per_rank_per_step"] > 0 and v["implied_gb_per_s_per_link"] > 0
+        # round-5 verdict, next 5b: the curve explains itself — the halves of a step, each measured alone
+        assert v["ingress_bytes_per_rank"] == v["ingress_bytes_per_rank_per_step"]
+        assert v["exchange_ms"] > 0 and v["kernel_ms"] > 0 and v["exchange_gb_per_s_per_link"] > 0
     assert by["whole_shards"]["ingress_bytes_per_rank_per_step"] == 500_000 * 64     # the other rank's shard
     assert "row-sharded" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
@@ -204,3 +208,36 @@ def test_two_rank_line_with_hot_rows_under_skewed_ids():
     assert "error" not in rs, rs
     assert d["n_gpus"] == 2 and d["value"] == rs["value"] > 0 and rs["ids"] == "zipf"
     assert "fixed" in rs["by_exchange"] and not rs["by_exchange"]["fixed"].get("overflow")
+
+
+def _run_bench(args, env_extra, timeout=300):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          timeout=timeout)
+
+
+def test_failed_process_group_init_is_one_error_line_and_a_nonzero_exit_code():
+    """round-5 verdict, next 5c: an RCCL / rendezvous failure must end as ONE JSON line with "error" and rc != 0, not as a
+    hang.  Rank 0 of a 2-rank job whose peer never arrives (no GPU needed: the device probe comes first on a GPU box, the
+    rendezvous time-out here)"""
+    import torch
+    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                   {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29741",
+                    "ARMNET_BENCH_BACKEND": "gloo", "ARMNET_BENCH_INIT_TIMEOUT": "3", "ARMNET_BENCH_DEVICE": "0"}, timeout=120)
+    d = _one_json_line(p.stdout)
+    assert p.returncode != 0 and d["value"] is None and d["n_gpus"] == 2 and d["rc"] == p.returncode
+    assert d["error_kind"] == ("init" if torch.cuda.is_available() else "device") and d["error"]
+
+
+def test_world_size_mismatch_and_launch_timeout_are_error_lines():
+    p = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
+    d = _one_json_line(p.stdout)
+    assert p.returncode == 7 and d["error_kind"] == "ranks" and "WORLD_SIZE=2" in d["error"]
+    # the self-launch (`python bench.py --gpus 2`, no torchrun) kills a job that does not finish in time
+    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                   {"ARMNET_BENCH_LAUNCH_TIMEOUT": "0.5", "ARMNET_BENCH_BACKEND": "gloo", "ARMNET_BENCH_DEVICE": "0"}, timeout=120)
+    d = _one_json_line(p.stdout)
+    assert p.returncode == 3 and d["error_kind"] == "launch_timeout" and d["value"] is None
