@@ -191,6 +191,35 @@ class _EntmaxFn(torch.autograd.Function):
         return dX, None, None, None, None, None
 
 
+def entmax_rows_forward(X, alpha, dim=-1, n_iter=50, ensure_sum_one=True):
+    """utils/entmax.py:31-36 with a TENSOR alpha: broadcast over every dimension of X but `dim` (its extent along `dim` must
+    be 1), every row solved with its own alpha by the reference's bisection (armnet_entmax_rows_f32).  Forward only: neither
+    the Jacobian-vector product with per-row alpha nor the gradient with respect to alpha (entmax.py:82-98) is provided, so a
+    call that would need either raises."""
+    if torch.is_grad_enabled() and (X.requires_grad or alpha.requires_grad):
+        raise NotImplementedError("entmax_bisect with a tensor alpha is forward-only here (no gradient w.r.t. X or alpha): "
+                                  "call it under torch.no_grad(), or pass a float alpha")
+    nd = X.dim()
+    dim = dim % nd
+    shape = list(X.shape)
+    shape[dim] = 1
+    al = alpha.to(dtype=X.dtype, device=X.device).expand(*shape)       # entmax.py:33-36
+    if not X.is_cuda:
+        from . import host_ops
+        with torch.no_grad():
+            return host_ops.entmax_bisect(X, al, dim, n_iter, ensure_sum_one)
+    if X.dtype != torch.float32:
+        raise native.ArmnetNativeError(f"entmax: float32 only, got {X.dtype}")
+    last = dim == nd - 1
+    Xt = (X if last else X.movedim(dim, -1)).contiguous()
+    at = (al if last else al.movedim(dim, -1)).contiguous().view(-1)
+    d = Xt.shape[-1]
+    P = torch.empty_like(Xt)
+    if Xt.numel():
+        native.entmax_rows(Xt.numel() // d, d, at, n_iter, ensure_sum_one, Xt, P)
+    return P if last else P.movedim(-1, dim)
+
+
 def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0):
     """utils/entmax.py:134 — alpha-entmax over `dim` (softmax when alpha == 1); differentiable in X."""
     if torch.is_grad_enabled() and X.requires_grad:

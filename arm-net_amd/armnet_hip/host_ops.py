@@ -50,11 +50,17 @@ def entmax_bisect(X, alpha, dim=-1, n_iter=50, ensure_sum_one=True):
     """utils/entmax.py:29-68 statement for statement on ATen ops (softmax when alpha == 1, as armnet_1h.py:12 builds it):
     alpha as a broadcast TENSOR (the reference's `pow` is tensor-tensor), tau_lo = max - 1, tau_hi = max - (1/d)^(alpha-1),
     n_iter halvings keeping the side on which f has the sign of f_lo, p of the LAST tau_m, renormalised."""
-    if alpha == 1.0:
-        return torch.softmax(X, dim=dim)
-    Xm = X.movedim(dim, -1) if dim % X.dim() != X.dim() - 1 else X
+    moved = dim % X.dim() != X.dim() - 1
+    if torch.is_tensor(alpha) and alpha.numel() != 1:
+        # entmax.py:31-36: a tensor alpha, already expanded to X's shape with extent 1 along `dim`
+        Xm = X.movedim(dim, -1) if moved else X
+        al = (alpha.movedim(dim, -1) if moved else alpha).to(Xm.dtype)
+    else:
+        if float(alpha) == 1.0:
+            return torch.softmax(X, dim=dim)
+        Xm = X.movedim(dim, -1) if moved else X
+        al = torch.full((1,) * Xm.dim(), float(alpha), dtype=Xm.dtype, device=Xm.device).expand(*Xm.shape[:-1], 1)
     d = Xm.shape[-1]
-    al = torch.full((1,) * Xm.dim(), float(alpha), dtype=Xm.dtype, device=Xm.device).expand(*Xm.shape[:-1], 1)
     am1 = al - 1
     inv = 1 / am1
     Xs = Xm * am1

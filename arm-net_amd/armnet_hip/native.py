@@ -37,7 +37,7 @@ EXPORTS = (
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
     "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
-    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32",
+    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32", "armnet_entmax_rows_f32",
 )
 
 _lib = None
@@ -211,6 +211,14 @@ def clamp_vals(vals):
     _dev_f32(vals, "vals")
     with _on(vals):
         check(load().armnet_clamp_vals_f32(_ptr(vals), ctypes.c_int64(vals.numel()), _stream()))
+
+
+def entmax_rows(rows, d, alpha_rows, n_iter, ensure_sum_one, X, P):
+    """armnet_entmax_rows_f32: one alpha per row (alpha_rows [rows] float32 on the device, all > 1), the reference's bisection"""
+    _dev_f32(X, "X"); _dev_f32(P, "P"); _dev_f32(alpha_rows, "alpha_rows")
+    with _on(X, P, alpha_rows):
+        check(load().armnet_entmax_rows_f32(ctypes.c_int64(rows), d, _ptr(alpha_rows), int(n_iter), int(bool(ensure_sum_one)),
+                                            _ptr(X), _ptr(P), _stream()))
 
 
 def entmax(rows, d, alpha, n_iter, ensure_sum_one, flags, X, P):

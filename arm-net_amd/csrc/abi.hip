@@ -188,7 +188,17 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
     if (rows < 0 || d <= 0 || n_iter < 0 || !X || !P) return ARMNET_ERR_BAD_ARG;
     if (!(alpha >= 1.0f)) return ARMNET_ERR_BAD_ARG;
     const SparseMapCfg cfg = make_sparse_cfg(alpha, n_iter, d, ensure_sum_one, flags);
-    return launch_entmax(rows, d, cfg, X, P, (hipStream_t)stream);
+    return launch_entmax(rows, d, cfg, nullptr, X, P, (hipStream_t)stream);
+}
+
+int armnet_entmax_rows_f32(int64_t rows, int d, const float* alpha_rows, int n_iter, int ensure_sum_one, const float* X,
+                           float* P, void* stream) {
+    if (rows < 0 || d <= 0 || n_iter < 0) return ARMNET_ERR_BAD_ARG;
+    if (rows == 0) return ARMNET_OK;
+    if (!alpha_rows || !X || !P) return ARMNET_ERR_BAD_ARG;
+    // the per-row fields of the configuration are filled in by the kernel (row_cfg); alpha = 3 only selects the bisection
+    const SparseMapCfg cfg = make_sparse_cfg(3.0f, n_iter, d, ensure_sum_one, ARMNET_F_FAITHFUL_BISECT);
+    return launch_entmax(rows, d, cfg, alpha_rows, X, P, (hipStream_t)stream);
 }
 
 int armnet_entmax_bwd_f32(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, void* stream) {

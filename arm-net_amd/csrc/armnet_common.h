@@ -364,7 +364,7 @@ bool fused_bwd_mfma_supports(int F, int E, int O);
 int launch_gather_scale(int64_t n_rows, int E, const void* ids, int id_type, const float* vals,
                         const float* table, int64_t nfeat, float* out, int32_t* id_status, hipStream_t s);
 int launch_clamp_vals(float* vals, int64_t n, hipStream_t s);
-int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, float* P, hipStream_t s);
+int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* alpha_rows, const float* X, float* P, hipStream_t s);
 int launch_entmax_bwd(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, hipStream_t s);
 size_t shard_route_ws_bytes(int64_t n, int R);
 int launch_shard_route(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* counts,

@@ -188,10 +188,23 @@ int launch_clamp_vals(float* vals, int64_t n, hipStream_t s) {
 // A block owns TPB consecutive rows = one contiguous span of TPB*d floats: it is read coalesced,
 // transposed through LDS so that thread r owns row r as the LDS column  lds[i*(TPB+1) + r]
 // (odd stride: conflict-free both for the transposing writes and the per-thread column reads).
+// alpha_rows != NULL (armnet_entmax_rows_f32): a per-ROW alpha (utils/entmax.py:31-36: an alpha tensor broadcast over
+// every dimension but `dim`); each row runs the reference's bisection with its own alpha - 1, 1 / (alpha - 1) and
+// (1 / d)^(alpha - 1) (entmax.py:42-47) — the Newton shortcuts are per-launch choices and stay with the scalar entry point
+__device__ inline SparseMapCfg row_cfg(const SparseMapCfg& cfg, const float* alpha_rows, int64_t row, int d) {
+    if (!alpha_rows) return cfg;
+    SparseMapCfg c = cfg;
+    c.mode = SOLVE_BISECT;
+    c.am1 = alpha_rows[row] - 1.0f;
+    c.r = 1.0f / c.am1;
+    c.tau_hi_off = powf(1.0f / (float)d, c.am1);
+    return c;
+}
+
 constexpr int EL_U = 8;
 template <int TPB>
-__global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ X,
-                                  float* __restrict__ P) {
+__global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ alpha_rows,
+                                  const float* __restrict__ X, float* __restrict__ P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = TPB + 1;
     for (int64_t r0 = (int64_t)blockIdx.x * TPB; r0 < rows; r0 += (int64_t)gridDim.x * TPB) {
@@ -217,7 +230,7 @@ __global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const f
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < nr) sparse_map_row(lds + threadIdx.x, S, d, cfg);
+        if ((int)threadIdx.x < nr) sparse_map_row(lds + threadIdx.x, S, d, row_cfg(cfg, alpha_rows, r0 + threadIdx.x, d));
         __syncthreads();
         float* dst = P + r0 * d;
         {
@@ -232,33 +245,33 @@ __global__ void entmax_lds_kernel(int64_t rows, int d, SparseMapCfg cfg, const f
 }
 
 // Fallback for very long rows: one thread per row, in place in global memory.
-__global__ void entmax_global_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ X,
-                                     float* __restrict__ P) {
+__global__ void entmax_global_kernel(int64_t rows, int d, SparseMapCfg cfg, const float* __restrict__ alpha_rows,
+                                     const float* __restrict__ X, float* __restrict__ P) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
          r += (int64_t)gridDim.x * blockDim.x) {
         float* p = P + r * d;
         const float* x = X + r * d;
         for (int i = 0; i < d; ++i) p[i] = x[i];
-        sparse_map_row(p, 1, d, cfg);
+        sparse_map_row(p, 1, d, row_cfg(cfg, alpha_rows, r, d));
     }
 }
 
-int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* X, float* P, hipStream_t s) {
+int launch_entmax(int64_t rows, int d, const SparseMapCfg& cfg, const float* alpha_rows, const float* X, float* P, hipStream_t s) {
     if (rows == 0) return ARMNET_OK;
     const size_t lds128 = (size_t)d * 129 * sizeof(float);
     const size_t lds64 = (size_t)d * 65 * sizeof(float);
     if (lds128 <= 64 * 1024) {
         int64_t grid = (rows + 127) / 128;
         if (grid > 256 * 8) grid = 256 * 8;
-        entmax_lds_kernel<128><<<(int)grid, 128, lds128, s>>>(rows, d, cfg, X, P);
+        entmax_lds_kernel<128><<<(int)grid, 128, lds128, s>>>(rows, d, cfg, alpha_rows, X, P);
     } else if (lds64 <= 64 * 1024) {
         int64_t grid = (rows + 63) / 64;
         if (grid > 256 * 8) grid = 256 * 8;
-        entmax_lds_kernel<64><<<(int)grid, 64, lds64, s>>>(rows, d, cfg, X, P);
+        entmax_lds_kernel<64><<<(int)grid, 64, lds64, s>>>(rows, d, cfg, alpha_rows, X, P);
     } else {
         int64_t grid = (rows + 63) / 64;
         if (grid > 4096) grid = 4096;
-        entmax_global_kernel<<<(int)grid, 64, 0, s>>>(rows, d, cfg, X, P);
+        entmax_global_kernel<<<(int)grid, 64, 0, s>>>(rows, d, cfg, alpha_rows, X, P);
     }
     ARMNET_LAUNCH_CHECK();
     return ARMNET_OK;

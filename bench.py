@@ -272,6 +272,7 @@ def host_twin(a, model):
         from models.armnet import ARMNetModel
         m = ARMNetModel(a.nfield, nfeat, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, ens, 2, 256)
     m.load_state_dict(sd, strict=True)
+    m.allow_host = True                         # the host branch is the point here (no "forgotten .cuda()" warning)
     return m.eval()
 
 

@@ -309,6 +309,7 @@ def main():
               16, 84, True)
     entmax_cases()
     entmax_grad_cases()
+    entmax_row_alpha_cases()
     run_sh_cases()
     more_cases()
     run_sh_grad_cases()
@@ -630,8 +631,40 @@ def round4_mid_width_grad_cases():
     grad_case("h4_grad_frappe_1h_e24_h20_a1.5_evalbn", "1h", base(10, 300, 24, 1.5, 20), 32, 146, False)
 
 
+def entmax_row_alpha_cases():
+    """round 6 (round-5 verdict, next 7): utils/entmax.py:31-36 — `alpha` as a TENSOR that broadcasts over every dimension
+    of X but `dim` (one alpha per row).  The reference's own outputs for gates of three scales, alpha per row in (1.05, 2.6),
+    the last dimension and an inner one, a partially broadcast alpha, n_iter 50 and 12, ensure_sum_one on and off."""
+    g = torch.Generator().manual_seed(606)
+    out = {}
+    meta = []
+
+    def case(key, X, alpha, dim, n_iter=50, ensure=True):
+        with torch.no_grad():
+            P = ref_entmax_bisect(X, alpha=alpha, dim=dim, n_iter=n_iter, ensure_sum_one=ensure)
+        out["X/" + key], out["A/" + key], out["P/" + key] = X.numpy(), alpha.numpy(), P.numpy()
+        meta.append({"key": key, "dim": dim, "n_iter": n_iter, "ensure_sum_one": ensure})
+
+    for scale in (0.05, 1.0, 6.0):
+        X = torch.randn(24, 16, 39, generator=g) * scale
+        case(f"rows_last_s{scale}", X, 1.05 + 1.55 * torch.rand(24, 16, 1, generator=g), -1)
+    X = torch.randn(16, 39, 24, generator=g) * 1.5
+    case("rows_dim1", X, 1.1 + 1.4 * torch.rand(16, 1, 24, generator=g), 1)
+    case("rows_partial_broadcast", X, 1.2 + torch.rand(39, 1, generator=g), -1)              # alpha [39, 1] against X [16, 39, 24]
+    case("rows_niter12", X, 1.1 + 1.4 * torch.rand(16, 39, 1, generator=g), -1, n_iter=12)
+    case("rows_no_renorm", X, 1.1 + 1.4 * torch.rand(16, 39, 1, generator=g), -1, ensure=False)
+    Xe = torch.randn(33, 1, generator=g)
+    case("rows_d1", Xe, 1.5 + torch.rand(33, 1, generator=g), -1)                            # d = 1: p = 1
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "g6c_entmax_row_alpha.npz")
+    np.savez_compressed(path, **out)
+    print(f"{'g6c_entmax_row_alpha':42s} {os.path.getsize(path) / 1024:8.1f} KiB  {len(meta)} cases")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--round4-only":         # add the round-4 cases without rewriting the others
+    if len(sys.argv) > 1 and sys.argv[1] == "--entmax-row-alpha-only":     # round 6: add without rewriting the others
+        entmax_row_alpha_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round4-only":         # add the round-4 cases without rewriting the others
         round4_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--siblings-only":
         sibling_cases()

@@ -28,3 +28,10 @@ def load_entmax():
     z = np.load(os.path.join(GOLDEN, "g6_entmax.npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     return [(m, z["X/" + m["key"]], z["P/" + m["key"]]) for m in meta]
+
+
+def load_entmax_row_alpha():
+    """round 6: utils/entmax.py:31-36 with a tensor alpha (one per row) — [(meta, X, alpha, P)] captured from the reference"""
+    z = np.load(os.path.join(GOLDEN, "g6c_entmax_row_alpha.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return [(m, z["X/" + m["key"]], z["A/" + m["key"]], z["P/" + m["key"]]) for m in meta]

@@ -204,6 +204,24 @@ def test_entmax_matches_reference_vectors():
     assert float(np.max(np.abs(got - want))) <= 2e-6
 
 
+def test_entmax_with_a_tensor_alpha_matches_reference_vectors():
+    """round 6 (round-5 verdict, next 7): utils/entmax.py:31-36 — alpha as a tensor that broadcasts over every dimension but
+    `dim`: one alpha per row through armnet_entmax_rows_f32 (the reference's bisection with per-row alpha - 1, 1 / (alpha - 1),
+    (1 / d)^(alpha - 1); t^r on the hardware exp2 / log2 pair: the bars of the scalar-alpha bisection)"""
+    from golden_util import load_entmax_row_alpha
+    from utils.entmax import entmax_bisect
+    for m, X, A, P in load_entmax_row_alpha():
+        with torch.no_grad():
+            got = entmax_bisect(torch.from_numpy(X).to(DEV), alpha=torch.from_numpy(A).to(DEV), dim=m["dim"], n_iter=m["n_iter"],
+                                ensure_sum_one=m["ensure_sum_one"]).cpu().numpy()
+        assert got.shape == P.shape
+        hi = np.broadcast_to(A > 2.0, P.shape) if A.ndim == P.ndim else np.broadcast_to((A > 2.0), P.shape)
+        err = np.abs(got - P)
+        assert float(err[~hi].max(initial=0.0)) <= 2e-6 and float(err[hi].max(initial=0.0)) <= 2e-5, m
+    with pytest.raises(NotImplementedError):                          # forward only
+        entmax_bisect(torch.randn(4, 5, device=DEV, requires_grad=True), alpha=torch.full((4, 1), 1.5, device=DEV))
+
+
 def test_entmax_edge_rows_on_device():
     from utils.entmax import entmax_bisect
     one_hot = entmax_bisect(torch.tensor([[5.0, 0.0, -1.0, 0.5]], device=DEV), 1.5).cpu().numpy()

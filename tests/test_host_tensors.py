@@ -186,3 +186,16 @@ def test_mixed_placement_raises_instead_of_computing_elsewhere():
     x = _x(ids, vals)
     with pytest.raises((native.ArmnetNativeError, RuntimeError)):
         m_host({"id": x["id"].cuda(), "value": x["value"].cuda()})
+
+
+def test_entmax_with_a_tensor_alpha_on_host_tensors_is_the_reference_bit_for_bit():
+    """utils/entmax.py:31-36 (one alpha per row) on host tensors: the reference's ATen ops in the reference's order"""
+    import numpy as np
+    import torch
+    from golden_util import load_entmax_row_alpha
+    from utils.entmax import entmax_bisect
+    for m, X, A, P in load_entmax_row_alpha():
+        with torch.no_grad():
+            got = entmax_bisect(torch.from_numpy(X), alpha=torch.from_numpy(A), dim=m["dim"], n_iter=m["n_iter"],
+                                ensure_sum_one=m["ensure_sum_one"]).numpy()
+        np.testing.assert_array_equal(got, P, err_msg=str(m))
