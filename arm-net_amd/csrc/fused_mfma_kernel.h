@@ -191,7 +191,10 @@ constexpr OccCfg occ_config(int E, int NQ, int MODE) {
 // ... and whether such a configuration also keeps the last evaluation's clamped differences (alpha = 2 / 1.5)
 constexpr bool occ_keeps(int E, int NQ, int SPW, int WPS) { return E == 16 && WPS >= 5 && occ_config(E, NQ, 0).spw == SPW; }
 
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM>
+// HOIST (round 6, one-sample groups of blocks with MANY 16-neuron passes): the pass-invariant A operands of both
+// contractions — MFMA #1's tile rows (NTILE x EB f32x4) and MFMA #2's transposed scalars (NQ x EB) — are read from the LDS
+// tile ONCE per group and kept in registers across the passes, instead of 3 + 10 LDS reads behind a fence in every pass.
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM, bool HOIST = false>
 __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel(FusedArgs a) {
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
     constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
@@ -553,6 +556,24 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         wave_lds_fence();
         PHASE(0);
 
+        f32x4 avh[HOIST ? EB * NTILE : 1];
+        float a2h[HOIST ? NQ * EB * SPW : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int kb = 0; kb < EB; ++kb)
+#pragma unroll
+                for (int t = 0; t < NTILE; ++t)
+                    avh[kb * NTILE + t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) {
+                        const int q = s * NQ + j;
+                        a2h[(j * EB + eb) * SPW + s] = xt[(16 * (q >> 2) + 4 * g + (q & 3)) * ES + 16 * eb + c];
+                    }
+        }
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 c1[NTILE];                  // gates, then the B operand of MFMA #2
             float kexp[SPW];                  // scale of the contraction's result
@@ -582,8 +603,10 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
                     f32x4 av[NTILE];
 #pragma unroll
-                    for (int t = 0; t < NTILE; ++t)
-                        av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                    for (int t = 0; t < NTILE; ++t) {
+                        if constexpr (HOIST) av[t] = avh[kb * NTILE + t];
+                        else av[t] = *reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 16 * kb + 4 * g);
+                    }
                     if (dbg_no_mfma) {
 #pragma unroll
                         for (int t = 0; t < NTILE; ++t) c1[t] = av[t] * bq;
@@ -939,7 +962,9 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     for (int s = 0; s < SPW; ++s) {
                         const int q = s * NQ + j;
                         const int row = 16 * (q >> 2) + 4 * g + (q & 3);
-                        float a2 = xt[row * ES + 16 * eb + c];
+                        float a2;
+                        if constexpr (HOIST) a2 = a2h[(j * EB + eb) * SPW + s];
+                        else a2 = xt[row * ES + 16 * eb + c];
                         // gc_arm.py:89: the interaction runs on emb_bn(exp(x)), field 4j+g of this lane group
                         if constexpr (MODEL == MODEL_GC_ARM) a2 = fmaf(__builtin_amdgcn_exp2f(a2 * L2E), es[0], es[1]);
                         if (dbg_no_mfma) {
@@ -1048,7 +1073,7 @@ static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, 
 }
 
 // One configuration (samples per wave-group, waves per SIMD) of a shape: sizes the block, launches the persistent grid.
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL>
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL, bool HOIST = false>
 static int launch_cfg(const FusedArgs& a, hipStream_t st) {
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
@@ -1090,7 +1115,7 @@ static int launch_cfg(const FusedArgs& a, hipStream_t st) {
         if (want < 1) want = 1;
     }
 #endif
-    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL>;
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL, HOIST>;
     ARMNET_ALLOW_BIG_LDS(kern, lds);
     kern<<<(int)want, 64 * wpb, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
@@ -1135,6 +1160,9 @@ static int launch_one(const FusedArgs& a, hipStream_t st) {
             return launch_cfg<E, NQ, oc.spw, MODE, SRC, oc.wps, MODEL>(a, st);
         } else {
             if (a.O <= 32) return launch_cfg<E, NQ, oc.spw, MODE, SRC, oc.wps, MODEL>(a, st);
+#ifdef ARMNET_HOIST_WIDE                        // A/B switch of the round-6 experiment (see HOIST above)
+            if (a.O >= 64) return launch_cfg<E, NQ, 1, MODE, SRC, 4, MODEL, true>(a, st);
+#endif
             return launch_cfg<E, NQ, SPW, MODE, SRC, WPS, MODEL>(a, st);
         }
     } else {

@@ -40,338 +40,12 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate
 
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--alpha", type=float, default=2.0)
-    ap.add_argument("--regime", choices=["fresh", "stress", "both"], default="both",
-                    help="fresh = the reference's initialisers (what `value` reports); stress = SURVEY §8c "
-                         "sparse-support weights; both = measure both, `value` from fresh")
-    ap.add_argument("--settle-ms", type=float, default=2500.0,
-                    help="untimed run of the step before the warm-up steps, so that the device clocks have settled")
-    ap.add_argument("--rotate", type=int, default=4,
-                    help="distinct (ids, vals, out) batches cycled through by the steps (working set > 256 MiB MALL)")
-    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step")
-    ap.add_argument("--nfield", type=int, default=39)
-    ap.add_argument("--nfeat", type=int, default=1_000_000)
-    ap.add_argument("--nemb", type=int, default=16)
-    ap.add_argument("--nhid", type=int, default=32)
-    ap.add_argument("--nhead", type=int, default=1, help=">1 selects models.armnet (multi-head)")
-    ap.add_argument("--ensemble", action="store_true",
-                    help="build the model with the DNN ensemble branch (BASELINE.json configs[4]); it only enters full_forward")
-    ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
-    ap.add_argument("--shard", choices=["replicate", "rows", "both"], default=None,
-                    help="replicate = every rank holds the table (no collective); rows = table row-sharded over "
-                         "the ranks, RCCL all-to-all lookup (SURVEY §8e); both (default when N > 1) = value from "
-                         "replicate plus a row_sharded object measured in the same run")
-    ap.add_argument("--dedup", choices=["auto", "on", "off"], default="auto",
-                    help="row-sharded variant: per-rank id de-duplication before the exchange")
-    ap.add_argument("--protocol", choices=["fixed", "exact"], default="fixed",
-                    help="row-sharded variant: fixed-capacity equal-split exchanges (no host sync) or exact splits")
-    ap.add_argument("--micro-batches", type=int, default=1,
-                    help="row-sharded variant: slices per step whose exchanges overlap the previous slice's kernel")
-    ap.add_argument("--whole-shard", choices=["auto", "off"], default="auto",
-                    help="row-sharded variant: all-gather the shards when the batch covers the table (auto) or always "
-                         "answer request lists (off)")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
-    ap.add_argument("--config4-capacity-factor", type=float, default=1.06,
-                    help="slot slack of the fixed-capacity exchange in the configs[3] measurement")
-    ap.add_argument("--hot-rows", type=int, default=0,
-                    help="row-sharded variant: rows [0, N) of the (frequency-ordered) id space are replicated on every rank "
-                         "and never routed (SURVEY §8e's hot-row lever; meaningful with --ids zipf)")
-    ap.add_argument("--no-config4", action="store_true",
-                    help="N > 1: skip the extra row-sharded measurement of BASELINE.json configs[3] (nfeat 100 M, nemb 64)")
-    ap.add_argument("--no-config5", action="store_true",
-                    help="N > 1: skip the data-parallel measurement of BASELINE.json configs[4] (armnet + DNN ensemble, Avazu shape)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-alphas", action="store_true", help="skip the alpha = 1.7 / 1.5 measurements reported beside `value`")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
-
-
-def build_model(a, device, rank=0, world=1, regime=None):
-    regime = regime or a.regime
-    torch.manual_seed(2025)                     # the reference's default seed (train.py:47)
-    # row-sharded runs never materialise the full table: the module gets a 16-row placeholder and the
-    # rank's shard is generated directly on the device below
-    nfeat_mod = 16 if a.shard == "rows" else a.nfeat
-    if a.nhead == 1:
-        from models.armnet_1h import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, bool(getattr(a, "ensemble", False)), 2, 256)
-    else:
-        from models.armnet import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat_mod, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, bool(getattr(a, "ensemble", False)), 2, 256)
-    if regime == "stress":
-        g = torch.Generator().manual_seed(7)
-        with torch.no_grad():
-            w = m.embedding.embedding.weight
-            w.copy_(torch.randn(w.shape, generator=g) * 0.5)
-            m.attn_layer.query.mul_(4.0)
-            m.arm_bn.running_mean.copy_(torch.rand(m.arm_bn.running_mean.shape, generator=g) + 0.5)
-            m.arm_bn.running_var.copy_(torch.rand(m.arm_bn.running_var.shape, generator=g) * 1.5 + 0.5)
-    m.eval()
-    # round 6: the default product path is what is timed — the in-kernel id range test is LIVE and its report deferred
-    # (block.IdStatus: a pinned host word, no host sync per step).  The row-sharded step's check is an all-reduce + host
-    # sync per call (every rank must raise together): off there, as in a serving loop that polls per N steps.
-    m.check_ids = a.shard != "rows"
-    m = m.to(device)
-    if a.shard == "rows":
-        from armnet_hip.sharded import RowShardedTable
-        n_local = (a.nfeat - rank + world - 1) // world
-        bound = (6.0 / (a.nfeat + a.nemb)) ** 0.5 if regime == "fresh" else 0.87    # xavier-uniform / stress
-        gdev = torch.Generator(device=device).manual_seed(2025 + rank)
-        shard = (torch.rand(n_local, a.nemb, device=device, generator=gdev) * 2 - 1) * bound
-        m._shard = RowShardedTable(shard, a.nfeat, None, protocol=a.protocol,
-                                   dedup={"auto": "auto", "on": True, "off": False}[a.dedup],
-                                   hot_rows=int(getattr(a, "hot_rows", 0)))
-        m._shard.micro_batches = a.micro_batches
-        m._shard.whole_shard = "auto" if getattr(a, "whole_shard", "auto") == "auto" else False
-        m.nfeat = a.nfeat
-    return m
-
-
-def make_batch(a, rank, device, k=0):
-    """batch k of rank `rank`: ids uniform (or Zipf) over nfeat, vals ~ U[0,1)"""
-    g = torch.Generator().manual_seed(2025 + 1000 * rank + 7919 * k)
-    if a.ids == "uniform":
-        ids = torch.randint(0, a.nfeat, (a.batch, a.nfield), generator=g, dtype=torch.int64)
-    else:                                       # Zipf(1.05)-like skew, reported separately
-        u = torch.rand(a.batch, a.nfield, generator=g, dtype=torch.float64)
-        ids = (a.nfeat ** u - 1).clamp_(0, a.nfeat - 1).to(torch.int64)
-    vals = torch.rand(a.batch, a.nfield, generator=g)
-    return ids.to(device), vals.to(device), ids, vals
-
-
-AGREE = [None]      # set by main() when ranks > 1: all ranks leave the pre-run at the same chunk
-
-
-def settle_clocks(fn, ms, cap_ms=None):
-    """Run the step, untimed, until the device clocks sit on a plateau.  A GPU that was idle takes some 50 ms of
-    sustained load before its clocks settle (measured: the same whole forward takes 230 us per batch in the first 30 ms
-    after idle and 204 us from then on); the first process on a freshly leased box has been seen to need SECONDS (round 4:
-    100-116 us per step for the first ~2 s, 87 us from then on, same kernel).  The K timed steps are a few milliseconds, so
-    without this they would measure the ramp of a cold device instead of the steady state of a serving loop.
-
-    Plateau (round-4 verdict, item 5): at least `ms` milliseconds AND the MEDIAN of the last 8 chunks of 64 steps within
-    1 % of the median of the 8 chunks before them AND within 1 % of the fastest such 8-chunk median seen so far (chunks
-    timed by HIP events on the current stream: the host clock around a 5 ms chunk is itself 1 % noisy).  Medians, because
-    single chunks on this device scatter by several per cent from one to the next (BENCH_r04: 5.8 % between windows,
-    which the round-4 rule — all of the last 8 chunks within 1 % of each other — could not reach in its 3 s cap); a clock
-    that is still creeping moves the 8-chunk median by more than 1 % per 8 chunks or it is not worth waiting for.
-    `ms` defaults to 2.5 s (round 5): every process on these boxes runs its first ~2 s of load on a FLAT slower level
-    (105 us per step, then 87 — profiles/r05_bench_n1_with_150ms_settle.json: a plateau test alone leaves the pre-run on
-    that level after 150 ms and the first window after it is 20 % slow; round 4 only got past it because its stricter
-    rule always ran into its 3 s cap).  Gives up after `cap_ms` (default 10 x ms).
-    Returns (chunks run, reached the plateau)."""
-    if ms <= 0:
-        return 0, True
-    cap_ms = cap_ms if cap_ms is not None else 10 * ms
-    t0 = time.perf_counter()
-    chunks = []
-    best8 = float("inf")
-    while True:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(64):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        chunks.append(e0.elapsed_time(e1))
-        elapsed = (time.perf_counter() - t0) * 1e3
-        flat = False
-        if len(chunks) >= 8:
-            m_last = median(chunks[-8:])
-            best8 = min(best8, m_last)
-            if len(chunks) >= 16:
-                m_prev = median(chunks[-16:-8])
-                flat = abs(m_last - m_prev) <= 0.01 * m_last and m_last <= 1.01 * best8
-        done = (elapsed >= ms and flat) or elapsed >= cap_ms
-        if AGREE[0] is not None:
-            done = AGREE[0](done)                 # a step may hold collectives: every rank runs the same number of chunks
-        if done:
-            SETTLE_NOISE[0] = (max(chunks[-8:]) - min(chunks[-8:])) / median(chunks[-8:]) if len(chunks) >= 8 else None
-            return len(chunks), bool(elapsed >= ms and flat)
-
-
-SETTLE_NOISE = [None]         # (max - min) / median of the last 8 chunks of the latest settle_clocks call
-
-
-def median(xs):
-    xs = sorted(xs)
-    n = len(xs)
-    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
-
-
-def timed(fn, steps, sync_all):
-    """Exactly `steps` calls bracketed by barrier + synchronize; wall ms and HIP-event ms."""
-    sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        fn()
-    ev1.record()
-    torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) * 1e3
-    sync_all()
-    return wall_ms, ev0.elapsed_time(ev1)
-
-
-def cpu_baseline(a, model, ids_cpu, vals_cpu):
-    """The CPU oracle (oracle/armnet_oracle.c, kind "port") on this host's cores, bounded sample."""
-    from oracle import armnet_oracle as orc
-    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    threads = orc.effective_cpus()              # affinity and cgroup CPU quota, not just the core count
-    orc.set_threads(threads)
-    variant = "1h" if a.nhead == 1 else "mh"
-    n = min(a.batch, 65536)
-    ids = ids_cpu[:n].numpy()
-    done, t_used, passes = 0, 0.0, 0
-    while t_used < a.cpu_seconds and passes < 3:
-        v = vals_cpu[:n].numpy().copy()
-        t0 = time.perf_counter()
-        orc.arm_block(variant, ids, v, sd, a.alpha)
-        t_used += time.perf_counter() - t0
-        done += n
-        passes += 1
-        if passes == 1 and t_used > a.cpu_seconds / 2:
-            break
-    # one-thread line (SURVEY §8d): a 2048-sample slice through the same entry point
-    orc.set_threads(1)
-    n1 = min(n, 2048)
-    v = vals_cpu[:n1].numpy().copy()
-    t0 = time.perf_counter()
-    orc.arm_block(variant, ids[:n1], v, sd, a.alpha)
-    t1 = time.perf_counter() - t0
-    orc.set_threads(threads)
-    out = {"value": done / t_used, "unit": "samples/s", "cores": threads, "kind": "port",
-           "sample": f"{passes} pass(es) of the first {n} samples of the same batch through "
-                     f"oracle_arm_block (50-step bisection, OpenMP, {threads} threads)",
-           "one_thread": {"value": n1 / t1, "unit": "samples/s", "sample": f"{n1} samples, 1 thread"}}
-    # SURVEY §8d (i): the reference's own ATen op chain on the same host threads, beside the C port (ii) above
-    try:
-        out["aten_chain"] = cpu_baseline_aten(a, model, ids_cpu, vals_cpu, threads)
-    except Exception as e:  # noqa: BLE001
-        out["aten_chain"] = {"error": f"{type(e).__name__}: {e}"}
-    return out
-
-
-def host_twin(a, model):
-    """the same module, never moved to the GPU: constructor arguments of `build_model`, the device model's state_dict"""
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    nfeat = sd["embedding.embedding.weight"].shape[0]
-    ens = bool(getattr(a, "ensemble", False))
-    if a.nhead == 1:
-        from models.armnet_1h import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat, a.nemb, a.alpha, a.nhid, a.nemb, 2, 256, 0.0, ens, 2, 256)
-    else:
-        from models.armnet import ARMNetModel
-        m = ARMNetModel(a.nfield, nfeat, a.nemb, a.nhead, a.alpha, a.nhid, 2, 256, 0.0, ens, 2, 256)
-    m.load_state_dict(sd, strict=True)
-    m.allow_host = True                         # the host branch is the point here (no "forgotten .cuda()" warning)
-    return m.eval()
-
-
-def aten_chain_block(host_model, ids, vals):
-    """SURVEY §8d CPU baseline (i): the reference's ATen OP CHAIN for rows a2..a9 on CPU tensors — what `train.py:117`
-    executes when the model sits on the host: the product module itself, never moved to the GPU, called with host
-    tensors (`armnet_hip/host_ops.py`: in-place clamp, embedding x value, key projection, gates, 50-step bisection entmax
-    with tensor-tensor `pow` (softmax when alpha == 1), value weighting, einsum + exp; then the eval-mode BatchNorm1d
-    module).  Held to the golden vectors by tests/test_host_tensors.py and tests/test_bench_contract.py."""
-    return host_model.arm_block(ids, vals)
-
-
-def cpu_baseline_aten(a, model, ids_cpu, vals_cpu, threads):
-    """the op chain above on `threads` host threads, on the first n samples of the same batch (about a.cpu_seconds)"""
-    host = host_twin(a, model)
-    old = torch.get_num_threads()
-    torch.set_num_threads(threads)
-    try:
-        n = min(a.batch, 2048)
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            aten_chain_block(host, ids_cpu[:n], vals_cpu[:n].clone())
-            t_probe = time.perf_counter() - t0
-            # size the sample so that it takes about cpu_seconds / 2 (the softmax branch is ~15x faster than bisection)
-            n = int(max(n, min(a.batch, n * (a.cpu_seconds / 2) / max(t_probe, 1e-6)))) // 1024 * 1024 or n
-            t0 = time.perf_counter()
-            aten_chain_block(host, ids_cpu[:n], vals_cpu[:n].clone())
-            t = time.perf_counter() - t0
-    finally:
-        torch.set_num_threads(old)
-    return {"value": n / t, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 pass of the first {n} samples of the same batch through the reference's ATen op chain — the product "
-                      f"module's own host-tensor branch (armnet_hip/host_ops.py: embedding, Linear/einsum, "
-                      f"{'softmax' if a.alpha == 1.0 else '50-step bisection entmax with tensor pow'}, "
-                      f"einsum, exp, BatchNorm1d) on CPU tensors, torch.set_num_threads({threads})"}
-
-
-def kernel_src_sha():
-    """hash of the fused forward kernel's sources: PMC traffic committed under profiles/ is only quoted for the
-    kernel it was measured on"""
-    h = hashlib.sha256()
-    for f in ("fused_mfma_kernel.h", "fused_mfma.hip", "armnet_common.h"):
-        with open(os.path.join(ROOT, "arm-net_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
-
-
-def committed_measurements(a, regime):
-    """HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and the access pattern's own ceiling
-    (tools/ubench/gather_stream) as committed under profiles/ for exactly this workload AND this kernel source;
-    counters cannot be read from inside the timed process.  (traffic, traffic_tag, pattern_ceiling_us, its source)"""
-    key = (f"nfield={a.nfield} nemb={a.nemb} nhid={a.nhid} nhead={a.nhead} B={a.batch} alpha={a.alpha} "
-           f"ids={a.ids} regime={regime} rotate={a.rotate}")
-    traffic = tag = ceil_us = ceil_src = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            for t in json.load(f)["entries"]:
-                if t["workload"] == key and t["kernel_src_sha"] == kernel_src_sha():
-                    traffic, tag = t["traffic_bytes_per_launch"], f"{t['source']} @ kernel_src_sha {t['kernel_src_sha']}"
-    except Exception:
-        pass
-    try:
-        with open(os.path.join(ROOT, "profiles", "access_pattern_ceiling.json")) as f:
-            for t in json.load(f)["entries"]:
-                if t["workload"] == f"nfield={a.nfield} nemb={a.nemb} nhid={a.nhid} nhead={a.nhead} B={a.batch}":
-                    ceil_us, ceil_src = t["us"], t["source"]
-    except Exception:
-        pass
-    return traffic, tag, ceil_us, ceil_src
-
-
-def live_pattern_ceiling(a):
-    """tools/ubench/gather_stream (built by __graft_entry__.build()) run NOW on this device: the fused block's memory
-    traffic and nothing else, rotating over 4 batches like the timed steps.  Only for the workload it implements (the
-    headline shape); None when the binary is not there."""
-    import re
-    import subprocess
-    exe = os.path.join(ROOT, "tools", "ubench", "gather_stream")
-    if not (os.path.exists(exe) and (a.nfield, a.nemb, a.nhid, a.nhead, a.batch, a.nfeat) == (39, 16, 32, 1, 65536, 1_000_000)):
-        return None
-    try:
-        out = subprocess.run([exe, str(max(1, a.rotate)), "quick"], capture_output=True, timeout=60).stdout.decode()
-        us = [float(m) for m in re.findall(r":\s*([0-9.]+) us", out)]
-        return min(us) if us else None
-    except Exception:
-        return None
-
-
-ERROR_RC = {"launch_timeout": 3, "init": 4, "device": 5, "deadline": 6, "ranks": 7}
-
-
-def error_line(a, what, msg, world=None):
-    """the ONE stdout line of a run that could not produce a number (round-5 verdict, next 5c: an RCCL failure must be a
-    line with "error" and a non-zero exit code, not a hang): the contract's keys with value = null"""
-    return {"metric": "samples/sec, ARM-Net forward (fused embedding + ARM interaction block), Criteo nfield=39 nemb=16 B=65536",
-            "value": None, "unit": "samples/s", "n_gpus": int(world if world is not None else a.gpus), "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "config": {"workload": "not measured"},
-            "error": f"{what}: {msg}", "error_kind": what, "rc": ERROR_RC[what]}
+# the parts live in benchlib/ (importable, testable); re-exported here so that `import bench` keeps its surface
+from benchlib.workload import parse, build_model, make_batch  # noqa: E402,F401
+from benchlib.timing import AGREE, SETTLE_NOISE, settle_clocks, median, timed  # noqa: E402,F401
+from benchlib.baselines import cpu_baseline, host_twin, aten_chain_block, cpu_baseline_aten  # noqa: E402,F401
+from benchlib.evidence import kernel_src_sha, committed_measurements, live_pattern_ceiling  # noqa: E402,F401
+from benchlib.errors import ERROR_RC, error_line  # noqa: E402,F401
 
 
 def main():
