@@ -37,7 +37,7 @@ EXPORTS = (
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
     "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
-    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32", "armnet_entmax_rows_f32", "armnet_linear_dw_f32",
+    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32", "armnet_entmax_rows_f32",
 )
 
 _lib = None
@@ -520,22 +520,6 @@ def mlp_head(B, K0, nhid, n_hidden, has_final, x, packed, out, flags=0):
         check(load().armnet_mlp_head_ex_f32(ctypes.c_int64(B), int(K0), int(nhid), int(n_hidden), int(has_final),
                                             _ptr(x), ctypes.c_int64(ldx), _ptr(packed), _ptr(out), ctypes.c_int64(ldo),
                                             ctypes.c_uint32(flags), _stream()))
-
-
-def linear_dw(dy, x, dw, db=None):
-    """dw[N, K] = dy^T x, db[N] = dy.sum(0) (armnet_linear_dw_f32: the weight gradient of nn.Linear, contraction over the rows
-    of dy [B, N] and x [B, K]); dw / db are overwritten"""
-    for t, n in ((dy, "dy"), (x, "x")):
-        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
-            raise ArmnetNativeError(f"{n}: expected a float32 2-d tensor with unit inner stride on the HIP device")
-    B, N = dy.shape
-    K = x.shape[1]
-    if x.shape[0] != B or tuple(dw.shape) != (N, K) or not dw.is_contiguous() or (db is not None and (db.numel() != N or not db.is_contiguous())):
-        raise ArmnetNativeError("linear_dw: shapes")
-    _dev_f32(dw, "dw")
-    with _on(dy, x, dw, db):
-        check(load().armnet_linear_dw_f32(ctypes.c_int64(B), int(N), int(K), _ptr(dy), ctypes.c_int64(dy.stride(0) if B > 1 else N),
-                                          _ptr(x), ctypes.c_int64(x.stride(0) if B > 1 else K), _ptr(dw), _ptr(db), _stream()))
 
 
 def linear_bf16x3(x, packed, out, K, N):

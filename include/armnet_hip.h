@@ -484,17 +484,6 @@ int armnet_linear_small_f32(int64_t B, int K, int N, const float* x, int64_t ldx
 int armnet_linear_bf16x3_f32(int64_t B, int K, int N, const float* x, int64_t ldx, const void* packed, float* out,
                              int64_t ldo, void* stream);
 
-/*
- * The WEIGHT gradient of nn.Linear on the matrix cores (round 6) — models/layers.py:68-88 under train.py:108-114, what autograd
- * computes as dY^T X for every Linear of the head:   dW[n, k] = sum_b dY[b, n] * X[b, k],   db[n] = sum_b dY[b, n].
- * dY [B, N] row stride ldy, X [B, K] row stride ldx (the Linear's input), dW [N, K] dense and db [N] (or NULL) are OVERWRITTEN
- * (zero-filled on the stream, then accumulated with float atomics: the summation order varies from run to run at fp32
- * rounding level, like the block's table gradient).  bf16 x 3 operand split, six cross products, fp32 accumulate
- * (csrc/linear_dw.hip): the error class of an fp32 GEMM.  Any N, K >= 1; the contraction is over the B samples.
- */
-int armnet_linear_dw_f32(int64_t B, int N, int K, const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW,
-                         float* db, void* stream);
-
 int armnet_mlp_head_supported(int K0, int nhid, int n_hidden);
 int64_t armnet_mlp_packed_bytes(int K0, int nhid, int n_hidden);
 int armnet_mlp_pack_layer_f32(int K0, int nhid, int n_hidden, int slot, const float* W, int Kin, const float* b,
