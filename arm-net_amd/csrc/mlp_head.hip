@@ -16,7 +16,8 @@
 //      6 bytes of packed planes per weight through the LDS ring, 3 instead of 5.5 vector-ALU operations per activation.
 //      Range: fp16 ends at 65 504.  The reference has no clamp behind exp (armnet_1h.py:86), so a first-layer input may
 //      be anything: every wave tracks max |c x| of what it splits, the block votes once after layer 1 and a block that
-//      met |c x| > 65 000 (|x| > 4 062) or inf REDOES its samples with the bf16 split below — same kernel, same launch,
+//      met |c x| > 65 000 (|x| > 4 062) or inf — or a wave of it nothing but |x| < 1e-3 (every low part subnormal) — REDOES its
+//      samples with the bf16 split below — same kernel, same launch,
 //      no host involvement, nothing stored before the vote.  (A sample's last bits therefore depend on whether a
 //      neighbour of its 128/256-sample block overflowed.)  Second-layer inputs cannot overflow: they are scaled per sample.
 //  * bf16 x 3 (rounds 2-5; the fallback, `flags & ARMNET_MLP_F_BF16X3`, and armnet_linear_bf16x3_f32): 6 products.
@@ -53,6 +54,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MLP_F16X2 = 2, MLP_BF16X3 = 3;
 constexpr float kXScale = 16.0f;        // first-layer activations are multiplied by this before the fp16 split
 constexpr float kXLimit = 65000.0f;     // a block that splits a scaled activation above this redoes its samples in bf16x3
+constexpr float kXTiny = 0.015625f;     // ... and so does a block whose LARGEST scaled activation is below 2^-6 (|x| < 1e-3 everywhere:
+                                        // the low fp16 part of every element would be subnormal — fp16's fixed 2^-24 spacing
+                                        // instead of a relative 2^-11 —; the bf16 split has fp32's exponent range)
 #ifndef ARMNET_MLP_DEPTH_F16
 #define ARMNET_MLP_DEPTH_F16 2
 #endif
@@ -571,7 +575,9 @@ __device__ __forceinline__ bool mlp_body(const MlpArgs& a) {
     if constexpr (P == MLP_F16X2) {
         // the block's vote on the fp16 range of what its waves split (inf included; a NaN poisons its own sample only,
         // as it does in the reference)
-        if (__builtin_amdgcn_ballot_w64(!(mx <= kXLimit)) != 0 && lane == 0) *vote = 1;
+        // (the all-tiny test is per WAVE: 32 samples x K0 inputs all below 1e-3 — dead or badly scaled inputs, not one quiet sample)
+        const bool out_of_range = __builtin_amdgcn_ballot_w64(!(mx <= kXLimit)) != 0 || __builtin_amdgcn_ballot_w64(mx >= kXTiny) == 0;
+        if (out_of_range && lane == 0) *vote = 1;
         block_barrier();
         if (*vote != 0) {
             wait_vm<0>();                               // the layer-2 prefetch must not land in the redo's ring

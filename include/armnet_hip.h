@@ -495,7 +495,7 @@ int armnet_mlp_head_f32(int64_t B, int K0, int nhid, int n_hidden, int has_final
  * Round 6: the head's operand split.  Default (armnet_mlp_head_f32 = flags 0): fp16 x 2 — activations and row-scaled
  * weights as hi + lo fp16 parts (round to nearest), THREE cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate,
  * exact power-of-two rescale — with an in-kernel range vote: a block whose first-layer inputs leave the fp16 range
- * (|x| > 4 062, inf) redoes its samples with the bf16 x 3 split (six products) inside the same launch.
+ * (|x| > 4 062, inf; or a wave of it nothing but |x| < 1e-3) redoes its samples with the bf16 x 3 split (six products) inside the same launch.
  * ARMNET_MLP_F_BF16X3 forces the bf16 x 3 split for every block (the rounds 2-5 kernel; A/B and bisecting).
  * Either way the result matches models/layers.py:68-88 evaluated in fp32 to fp32-GEMM class error.
  */
