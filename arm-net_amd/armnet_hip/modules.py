@@ -404,7 +404,7 @@ class ArmNetBase(nn.Module):
         sharded_arm_block's all-reduced flag.)"""
         self._id_status.poll(self.embedding.embedding.weight.device)
 
-    def shard_embedding(self, group=None, release_full=False, hot_rows=0):
+    def shard_embedding(self, group=None, release_full=False, hot_rows=0, data_groups=None):
         """Row-shard the ARM embedding table over the process group (multi-GPU): this rank
         keeps a COPY of rows i = rank (mod world); every later inference arm_block() call fetches rows by
         all-to-all.  The full table must be resident when this is called.
@@ -415,6 +415,9 @@ class ArmNetBase(nn.Module):
         seen — call shard_embedding() again after those).  With release_full=True the parameter's storage is
         replaced by an empty [0, nemb] tensor afterwards — that is what frees the memory; the shard is then the
         only copy (state_dict no longer holds the table).
+
+        data_groups (round 6): further process groups over the same ranks, one per step a serving loop keeps in flight on its
+        own stream — the exchanges of consecutive steps then run on different communicators and overlap (RowShardedTable).
 
         hot_rows = N (round 5): rows [0, N) — the head of a frequency-ordered id space, where skewed click logs put most
         lookups — are also kept REPLICATED on every rank (N * nemb * 4 bytes) and served without crossing a link
@@ -430,6 +433,7 @@ class ArmNetBase(nn.Module):
         p = self.embedding.embedding.weight
         w = p.detach()
         self._shard = RowShardedTable(shard_rows(w, rank, world), w.shape[0], group, hot_rows=hot_rows)
+        self._shard.data_groups = list(data_groups) if data_groups else None    # one communicator per stream in flight (sharded.py)
         self._shard_src = None if release_full else (p.data_ptr(), p._version)
         if release_full:
             p.data = torch.empty(0, w.shape[1], device=w.device, dtype=w.dtype)

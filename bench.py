@@ -379,7 +379,13 @@ def main():
         def run_sharded():
             try:
                 torch.cuda.set_device(local)
-                model.shard_embedding(hot_rows=a.hot_rows)
+                # the row-sharded step's id check is one all-reduce + host read per call (every rank has to raise together):
+                # off inside the timed steps, as in a serving loop that polls every N steps (`overflowed()` is checked after them)
+                model.check_ids = False
+                # one communicator per step in flight: the exchanges of consecutive steps then run on different RCCL streams
+                dgs = [dist.new_group() for _ in range(max(1, a.in_flight))] if (use_dist and a.in_flight > 1 and a.stream_communicators) else None
+                model.shard_embedding(hot_rows=a.hot_rows, data_groups=dgs)
+                sharded["communicators"] = len(dgs) if dgs else 1
                 model._shard.micro_batches = a.micro_batches
                 model._shard.protocol = a.protocol
                 model._shard.dedup = {"auto": "auto", "on": True, "off": False}[a.dedup]
@@ -400,6 +406,7 @@ def main():
                                by_in_flight=ok[best]["by_in_flight"], in_flight_err=ok[best].get("in_flight_err"))
             except Exception as e:  # noqa: BLE001
                 sharded["err"] = f"{type(e).__name__}: {e}"
+            model.check_ids = True
             sharded["done"] = True
 
         th = threading.Thread(target=run_sharded, daemon=True)
@@ -432,6 +439,8 @@ def main():
                 # is bound by the links, so the slots carry 6 % slack instead of the default 25 % (which is sized for
                 # skewed production ids); an overflow would void the number and is checked after the timed steps
                 m4._shard.capacity_factor = a.config4_capacity_factor
+                if a.in_flight > 1 and a.stream_communicators:
+                    m4._shard.data_groups = [dist.new_group() for _ in range(a.in_flight)]
                 b4 = [make_batch(a4, rank, dev, k)[:2] for k in range(NB)]
                 nfl = max(1, a.in_flight)
                 streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
@@ -711,7 +720,7 @@ def main():
             line["row_sharded"] = {
                 "value": world * a.batch * a.steps / (sharded_ms * 1e-3), "unit": "samples/s",
                 "ms_per_step": sharded_ms / a.steps, "steps_in_flight": sharded["in_flight"],
-                "exchange": sharded.get("exchange"), "ids": a.ids,
+                "exchange": sharded.get("exchange"), "ids": a.ids, "communicators": sharded.get("communicators", 1),
                 "by_exchange": {k: mode_obj(v) for k, v in sharded["modes"].items()},
                 "note": f"(= `value`: by_exchange.fixed, the request-list protocol north_star names, whenever it ran — NOT the "
                         f"faster of the two exchanges) the block with the table row-sharded (row i "

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--whole-shard", choices=["auto", "off"], default="auto",
                     help="row-sharded variant: all-gather the shards when the batch covers the table (auto) or always "
                          "answer request lists (off)")
+    ap.add_argument("--stream-communicators", action="store_true",
+                    help="row-sharded steps in flight get one process group (RCCL communicator) per stream instead of sharing one "
+                         "(RowShardedTable.data_groups; no gain through RCCL at world size 1 — unmeasured on several GPUs, so off)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="row-sharded variant: steps kept in flight on alternating streams (1 = one stream)")
     ap.add_argument("--config4-capacity-factor", type=float, default=1.06,

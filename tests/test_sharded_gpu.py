@@ -73,7 +73,7 @@ def test_two_ranks_on_one_gpu_are_bit_equal_to_replicated(dedup, micro, protocol
         assert ok, f"rank {rank}: sharded result differs from replicated by {err}"
 
 
-def _worker_in_flight(rank, world, port, q, whole):
+def _worker_in_flight(rank, world, port, q, whole, communicators=1):
     for p in (ROOT, os.path.join(ROOT, "arm-net_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -93,7 +93,8 @@ def _worker_in_flight(rank, world, port, q, whole):
         m.check_ids = False                                    # no host sync inside a step
         with torch.no_grad():
             want = [m.arm_block(i, v.clone()) for i, v in batches]
-            m.shard_embedding()
+            # round 6: one communicator per stream in flight (RowShardedTable.data_groups)
+            m.shard_embedding(data_groups=[dist.new_group() for _ in range(communicators)] if communicators > 1 else None)
             m._shard.dedup, m._shard.protocol, m._shard.whole_shard = True, "fixed", whole
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             for s in streams:
@@ -109,13 +110,15 @@ def _worker_in_flight(rank, world, port, q, whole):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("whole", ["auto", False])
-def test_steps_in_flight_on_two_streams_are_bit_equal_to_replicated(whole):
+@pytest.mark.parametrize("whole,communicators", [("auto", 1), (False, 1), ("auto", 2), (False, 2)])
+def test_steps_in_flight_on_two_streams_are_bit_equal_to_replicated(whole, communicators):
     """bench.py --in-flight 2: consecutive steps alternate between two streams; nothing but the overflow flag is shared
-    between steps (the de-duplication workspace is per stream)"""
+    between steps (the de-duplication workspace is per stream).  communicators = 2 (round 6): every stream's exchanges run on
+    their own process group, so that consecutive steps' collectives do not queue on one communicator's stream"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_in_flight, args=(r, 2, 29677 + (whole is False), q, whole)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, 2, 29677 + (whole is False) + 2 * (communicators > 1), q, whole, communicators))
+             for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
