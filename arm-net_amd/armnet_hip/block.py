@@ -32,8 +32,19 @@ class IdStatus:
     def __init__(self):
         self._word = None
 
+    # a copied / pickled module (copy.deepcopy for an EMA twin, torch.save(model)) gets a FRESH report of its own: the word is
+    # pinned memory tied to this process, and a plain copy of it would not be pinned
+    def __deepcopy__(self, memo):
+        return IdStatus()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._word = None
+
     def word(self):
-        if self._word is None:
+        if self._word is None or not self._word.is_pinned():
             self._word = torch.zeros(1, dtype=torch.int32).pin_memory()
         return self._word
 

@@ -945,3 +945,28 @@ def test_host_branch_warns_once_on_a_box_with_a_gpu():
         m2 = ARMNetModel(10, 50, 8, 1.7, 4, 8, 1, 8, 0.0, False, 1, 8).eval()
         m2.allow_host = True
         m2(x)
+
+
+def test_copied_and_pickled_models_get_their_own_id_report():
+    """the deferred id report lives in pinned host memory: copy.deepcopy / pickle of a model must not carry a plain copy of it"""
+    import copy
+    import io
+    meta, sd, ids, vals, _ = load("g2_criteo_1h_a2.0_stress")
+    m = build_model(meta, sd, DEV)
+    x = lambda: {"id": torch.from_numpy(ids).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)}
+    with torch.no_grad():
+        y = m(x())
+        m2 = copy.deepcopy(m)
+        assert m2._id_status is not m._id_status and m2.embedding._id_status is m2._id_status   # shared inside the copy
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        m3 = torch.load(buf, weights_only=False)
+        for mm in (m2, m3):
+            assert torch.equal(mm(x()), y)
+            bad = ids.copy()
+            bad[0, 0] = -5
+            mm({"id": torch.from_numpy(bad).to(DEV), "value": torch.from_numpy(vals.copy()).to(DEV)})
+            with pytest.raises(IndexError):
+                mm.poll()
+        m.poll()                                            # the original's report is untouched
