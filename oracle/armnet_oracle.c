@@ -203,6 +203,51 @@ void oracle_entmax_bisect(const float* X, int64_t rows, int d, float alpha, int 
     }
 }
 
+/* utils/entmax.py:29-68 with a TENSOR alpha (entmax.py:31-36: alpha broadcast over every dimension but `dim`, i.e. one alpha per
+ * row; round 6): the same statements with per-row  alpha - 1 (:42),  1 / (alpha - 1) (:22),  (1 / d) ** (alpha - 1) (:47). */
+void oracle_entmax_bisect_rows(const float* X, const float* alpha_rows, int64_t rows, int d, int n_iter, int ensure_sum_one,
+                               float* P) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float am1 = alpha_rows[r] - 1.0f;
+        const float inv_am1 = 1.0f / am1;
+        const float gp_invd = powf((float)(1.0 / (double)d), am1);
+        const float* x = X + r * d;
+        float* p = P + r * d;
+        float mx = -INFINITY;
+        int has_nan = 0;
+        for (int i = 0; i < d; ++i) {
+            const float v = x[i] * am1;
+            if (v != v) has_nan = 1;
+            if (v > mx) mx = v;
+        }
+        if (has_nan) mx = NAN;
+        float tau_lo = mx - 1.0f;
+        const float tau_hi = mx - gp_invd;
+        float f_lo = 0.f;
+        for (int i = 0; i < d; ++i) f_lo += entmax_p(x[i] * am1 - tau_lo, inv_am1);
+        f_lo -= 1.0f;
+        float dm = tau_hi - tau_lo;
+        for (int i = 0; i < d; ++i) p[i] = 0.f;
+        for (int it = 0; it < n_iter; ++it) {
+            dm *= 0.5f;
+            const float tau_m = tau_lo + dm;
+            float s = 0.f;
+            for (int i = 0; i < d; ++i) {
+                p[i] = entmax_p(x[i] * am1 - tau_m, inv_am1);
+                s += p[i];
+            }
+            const float f_m = s - 1.0f;
+            if (f_m * f_lo >= 0.f) tau_lo = tau_m;
+        }
+        if (ensure_sum_one) {
+            float s = 0.f;
+            for (int i = 0; i < d; ++i) s += p[i];
+            for (int i = 0; i < d; ++i) p[i] = p[i] / s;
+        }
+    }
+}
+
 /* nn.Softmax(dim=-1) — the alpha == 1 branch (models/armnet_1h.py:12). */
 void oracle_softmax(const float* X, int64_t rows, int d, float* P) {
 #pragma omp parallel for schedule(static)

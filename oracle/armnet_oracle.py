@@ -120,6 +120,17 @@ def entmax_bisect(X, alpha=1.5, n_iter=50, ensure_sum_one=True):
     return P
 
 
+def entmax_bisect_rows(X, alpha_rows, n_iter=50, ensure_sum_one=True):
+    """utils/entmax.py:31-36,134 with one alpha per row of the last dimension: X [..., d], alpha_rows broadcastable to X[..., :1]"""
+    X, pX = _f(X)
+    d = X.shape[-1]
+    rows = X.size // d
+    A = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_rows, np.float32), X.shape[:-1] + (1,)).reshape(rows))
+    P = np.empty_like(X)
+    lib().oracle_entmax_bisect_rows(pX, _fp(A), ctypes.c_int64(rows), d, int(n_iter), int(bool(ensure_sum_one)), _fp(P))
+    return P
+
+
 def softmax(X):
     X, pX = _f(X)
     d = X.shape[-1]

@@ -218,6 +218,15 @@ def test_entmax_with_a_tensor_alpha_matches_reference_vectors():
         hi = np.broadcast_to(A > 2.0, P.shape) if A.ndim == P.ndim else np.broadcast_to((A > 2.0), P.shape)
         err = np.abs(got - P)
         assert float(err[~hi].max(initial=0.0)) <= 2e-6 and float(err[hi].max(initial=0.0)) <= 2e-5, m
+    # ... and against the oracle's per-row restatement on inputs of another size (2 100 rows of 39 and of 7)
+    g = torch.Generator().manual_seed(3)
+    for d in (39, 7):
+        X = torch.randn(7, 300, d, generator=g) * 2.0
+        A = 1.05 + 0.95 * torch.rand(7, 300, 1, generator=g)
+        with torch.no_grad():
+            got = entmax_bisect(X.to(DEV), alpha=A.to(DEV)).cpu().numpy()
+        want = orc.entmax_bisect_rows(X.numpy(), A.numpy())
+        assert float(np.max(np.abs(got - want))) <= 2e-6
     with pytest.raises(NotImplementedError):                          # forward only
         entmax_bisect(torch.randn(4, 5, device=DEV, requires_grad=True), alpha=torch.full((4, 1), 1.5, device=DEV))
 

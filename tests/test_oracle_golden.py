@@ -57,6 +57,21 @@ def test_entmax_alone_matches_reference():
     assert worst < 2e-5
 
 
+def test_entmax_with_one_alpha_per_row_matches_reference():
+    """round 6: utils/entmax.py:31-36 (tensor alpha) — the oracle's per-row restatement against the reference's own vectors"""
+    from golden_util import load_entmax_row_alpha
+    for m, X, A, P in load_entmax_row_alpha():
+        nd = X.ndim
+        dim = m["dim"] % nd
+        Xl = np.moveaxis(X, dim, -1)
+        Al = np.moveaxis(np.broadcast_to(A, X.shape[:dim] + (1,) + X.shape[dim + 1:]) if A.ndim == nd else
+                         np.broadcast_to(A, np.broadcast_shapes(A.shape, tuple(1 if i == dim else n for i, n in enumerate(X.shape)))), dim, -1)
+        got = np.moveaxis(orc.entmax_bisect_rows(np.ascontiguousarray(Xl), np.ascontiguousarray(Al), m["n_iter"], m["ensure_sum_one"]), -1, dim)
+        hi = np.broadcast_to(np.moveaxis(Al, -1, dim) > 2.0, P.shape)
+        err = np.abs(got - P)
+        assert float(err[~hi].max(initial=0.0)) <= 2e-6 and float(err[hi].max(initial=0.0)) <= 2e-5, (m, float(err.max()))
+
+
 def test_entmax_edge_rows():
     one_hot = orc.entmax_bisect(np.array([[5.0, 0.0, -1.0, 0.5]], np.float32), 1.5)
     np.testing.assert_array_equal(one_hot, [[1, 0, 0, 0]])
