@@ -202,25 +202,15 @@ class _EntmaxFn(torch.autograd.Function):
         return dX, None, None, None, None, None
 
 
-def entmax_rows_forward(X, alpha, dim=-1, n_iter=50, ensure_sum_one=True):
-    """utils/entmax.py:31-36 with a TENSOR alpha: broadcast over every dimension of X but `dim` (its extent along `dim` must
-    be 1), every row solved with its own alpha by the reference's bisection (armnet_entmax_rows_f32).  Forward only: neither
-    the Jacobian-vector product with per-row alpha nor the gradient with respect to alpha (entmax.py:82-98) is provided, so a
-    call that would need either raises."""
-    if torch.is_grad_enabled() and (X.requires_grad or alpha.requires_grad):
-        raise NotImplementedError("entmax_bisect with a tensor alpha is forward-only here (no gradient w.r.t. X or alpha): "
-                                  "call it under torch.no_grad(), or pass a float alpha")
-    nd = X.dim()
-    dim = dim % nd
-    shape = list(X.shape)
-    shape[dim] = 1
-    al = alpha.to(dtype=X.dtype, device=X.device).expand(*shape)       # entmax.py:33-36
+def _entmax_rows_raw(X, al, dim, n_iter, ensure_sum_one):
+    """X and al (alpha expanded to X's shape with extent 1 along `dim`): the per-row sparse map, no autograd"""
     if not X.is_cuda:
         from . import host_ops
         with torch.no_grad():
             return host_ops.entmax_bisect(X, al, dim, n_iter, ensure_sum_one)
     if X.dtype != torch.float32:
         raise native.ArmnetNativeError(f"entmax: float32 only, got {X.dtype}")
+    nd = X.dim()
     last = dim == nd - 1
     Xt = (X if last else X.movedim(dim, -1)).contiguous()
     at = (al if last else al.movedim(dim, -1)).contiguous().view(-1)
@@ -229,6 +219,52 @@ def entmax_rows_forward(X, alpha, dim=-1, n_iter=50, ensure_sum_one=True):
     if Xt.numel():
         native.entmax_rows(Xt.numel() // d, d, at, n_iter, ensure_sum_one, Xt, P)
     return P if last else P.movedim(-1, dim)
+
+
+class _EntmaxRowsFn(torch.autograd.Function):
+    """entmax with a TENSOR alpha, differentiable in X and in alpha (utils/entmax.py:70-98): forward = the per-row map
+    (armnet_entmax_rows_f32 on the device, the reference's op chain on host tensors); backward = the reference's formulas on
+    the saved output as tensor ops on whatever device the tensors live on — the Jacobian-vector product with gppr = Y^(2 - alpha)
+    on the support, and the alpha gradient from the Shannon terms (entmax.py:82-98; "ensure alpha is not close to 1")."""
+
+    @staticmethod
+    def forward(ctx, X, al, dim, n_iter, ensure_sum_one):
+        Y = _entmax_rows_raw(X.detach(), al.detach(), dim, n_iter, ensure_sum_one)
+        ctx.save_for_backward(Y, al.detach())
+        ctx.dim = dim
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        Y, al = ctx.saved_tensors
+        dim = ctx.dim
+        zero = Y.new_zeros(())
+        gppr = torch.where(Y > 0, Y ** (2 - al), zero)
+        gs = gppr.sum(dim, keepdim=True)
+        dX = dY * gppr
+        dX = dX - (dX.sum(dim, keepdim=True) / gs) * gppr
+        d_al = None
+        if ctx.needs_input_grad[1]:
+            S = torch.where(Y > 0, Y * torch.log(Y), zero)
+            ent = S.sum(dim, keepdim=True)
+            Ysk = gppr / gs
+            d_al = (dY * (Y - Ysk) / ((al - 1) ** 2) - dY * (S - Ysk * ent) / (al - 1)).sum(dim, keepdim=True)
+        return dX, d_al, None, None, None
+
+
+def entmax_rows_forward(X, alpha, dim=-1, n_iter=50, ensure_sum_one=True):
+    """utils/entmax.py:31-36 with a TENSOR alpha: broadcast over every dimension of X but `dim` (its extent along `dim` must
+    be 1), every row solved with its own alpha by the reference's bisection (armnet_entmax_rows_f32).  Differentiable in X and
+    in alpha (round 6: _EntmaxRowsFn — the expand to X's shape is a torch op, so autograd reduces the gradient to alpha's own
+    shape exactly as it does for the reference)."""
+    nd = X.dim()
+    dim = dim % nd
+    shape = list(X.shape)
+    shape[dim] = 1
+    al = alpha.to(dtype=X.dtype, device=X.device).expand(*shape)       # entmax.py:33-36
+    if torch.is_grad_enabled() and (X.requires_grad or al.requires_grad):
+        return _EntmaxRowsFn.apply(X, al, dim, n_iter, ensure_sum_one)
+    return _entmax_rows_raw(X, al, dim, n_iter, ensure_sum_one)
 
 
 def entmax_forward(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True, flags=0):

@@ -5,8 +5,8 @@ keep the reference's names, argument meaning and defaults (entmax.py:134,238-275
 armnet_entmax_f32.  With n_iter >= 24 and alpha <= 2 the HIP kernel solves the same threshold root by
 Newton/Michelot iterations (result within ~1e-6 of the 50-step bisection); otherwise it runs the
 reference's bisection step for step.  Differentiable in X (the Jacobian-vector product of
-entmax.py:70-80 on the saved output); the gradient with respect to alpha (entmax.py:82-98) is not provided.  A TENSOR
-alpha (entmax.py:31-36: one alpha per row) runs the reference's bisection per row, forward only (round 6).
+entmax.py:70-80 on the saved output).  A TENSOR alpha (entmax.py:31-36: one alpha per row; or any alpha tensor that requires
+grad) runs the reference's bisection per row and is differentiable in X AND in alpha (entmax.py:82-98) (round 6).
 """
 import torch.nn as nn
 
@@ -15,8 +15,9 @@ from armnet_hip.block import entmax_forward, entmax_rows_forward
 
 def entmax_bisect(X, alpha=1.5, dim=-1, n_iter=50, ensure_sum_one=True):
     if not isinstance(alpha, (int, float)):
-        if alpha.numel() != 1:
-            # entmax.py:31-36: a tensor alpha, broadcast over every dimension but `dim` — one alpha per row (round 6)
+        if alpha.numel() != 1 or alpha.requires_grad:
+            # entmax.py:31-36: a tensor alpha, broadcast over every dimension but `dim` — one alpha per row — or an alpha that
+            # wants its gradient (entmax.py:82-98) (round 6)
             return entmax_rows_forward(X, alpha, dim=dim, n_iter=n_iter, ensure_sum_one=ensure_sum_one)
         alpha = float(alpha)
     return entmax_forward(X, float(alpha), dim=dim, n_iter=n_iter, ensure_sum_one=ensure_sum_one)

@@ -169,7 +169,7 @@ int armnet_entmax_f32(int64_t rows, int d, float alpha, int n_iter, int ensure_s
  * The same with one alpha PER ROW (round 6) — utils/entmax.py:31-36: `alpha` may be a tensor that broadcasts over every
  * dimension of X but `dim`; the host wrapper expands it to alpha_rows [rows] (all > 1, as the reference requires).  Every row
  * runs the reference's n_iter-step bisection (entmax.py:44-64) with its own alpha - 1, 1 / (alpha - 1), (1 / d)^(alpha - 1).
- * The gradient with respect to alpha (entmax.py:82-98) is not provided.
+ * The gradients (entmax.py:70-98, with respect to X and to alpha) are tensor operations on P in the host wrapper (armnet_hip/block.py).
  */
 int armnet_entmax_rows_f32(int64_t rows, int d, const float* alpha_rows, int n_iter, int ensure_sum_one, const float* X,
                            float* P, void* stream);

@@ -643,11 +643,16 @@ def entmax_row_alpha_cases():
         with torch.no_grad():
             P = ref_entmax_bisect(X, alpha=alpha, dim=dim, n_iter=n_iter, ensure_sum_one=ensure)
         out["X/" + key], out["A/" + key], out["P/" + key] = X.numpy(), alpha.numpy(), P.numpy()
+        # the reference's own gradients with respect to X and to alpha (entmax.py:70-98) for a random dY
+        Xg, Ag = X.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+        dY = torch.randn(X.shape, generator=g)
+        (ref_entmax_bisect(Xg, alpha=Ag, dim=dim, n_iter=n_iter, ensure_sum_one=ensure) * dY).sum().backward()
+        out["dY/" + key], out["dX/" + key], out["dA/" + key] = dY.numpy(), Xg.grad.numpy(), Ag.grad.numpy()
         meta.append({"key": key, "dim": dim, "n_iter": n_iter, "ensure_sum_one": ensure})
 
     for scale in (0.05, 1.0, 6.0):
-        X = torch.randn(24, 16, 39, generator=g) * scale
-        case(f"rows_last_s{scale}", X, 1.05 + 1.55 * torch.rand(24, 16, 1, generator=g), -1)
+        X = torch.randn(16, 12, 39, generator=g) * scale
+        case(f"rows_last_s{scale}", X, 1.05 + 1.55 * torch.rand(16, 12, 1, generator=g), -1)
     X = torch.randn(16, 39, 24, generator=g) * 1.5
     case("rows_dim1", X, 1.1 + 1.4 * torch.rand(16, 1, 24, generator=g), 1)
     case("rows_partial_broadcast", X, 1.2 + torch.rand(39, 1, generator=g), -1)              # alpha [39, 1] against X [16, 39, 24]
@@ -655,6 +660,7 @@ def entmax_row_alpha_cases():
     case("rows_no_renorm", X, 1.1 + 1.4 * torch.rand(16, 39, 1, generator=g), -1, ensure=False)
     Xe = torch.randn(33, 1, generator=g)
     case("rows_d1", Xe, 1.5 + torch.rand(33, 1, generator=g), -1)                            # d = 1: p = 1
+    case("scalar_alpha_tensor", torch.randn(8, 16, 39, generator=g), torch.tensor(1.7), -1)      # a 0-dim alpha that wants its gradient
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "g6c_entmax_row_alpha.npz")
     np.savez_compressed(path, **out)

@@ -35,3 +35,10 @@ def load_entmax_row_alpha():
     z = np.load(os.path.join(GOLDEN, "g6c_entmax_row_alpha.npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     return [(m, z["X/" + m["key"]], z["A/" + m["key"]], z["P/" + m["key"]]) for m in meta]
+
+
+def load_entmax_row_alpha_grads():
+    """... and the reference's gradients for a random dY: [(meta, X, alpha, dY, dX, dalpha)]"""
+    z = np.load(os.path.join(GOLDEN, "g6c_entmax_row_alpha.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return [(m, z["X/" + m["key"]], z["A/" + m["key"]], z["dY/" + m["key"]], z["dX/" + m["key"]], z["dA/" + m["key"]]) for m in meta]

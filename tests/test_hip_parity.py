@@ -227,8 +227,17 @@ def test_entmax_with_a_tensor_alpha_matches_reference_vectors():
             got = entmax_bisect(X.to(DEV), alpha=A.to(DEV)).cpu().numpy()
         want = orc.entmax_bisect_rows(X.numpy(), A.numpy())
         assert float(np.max(np.abs(got - want))) <= 2e-6
-    with pytest.raises(NotImplementedError):                          # forward only
-        entmax_bisect(torch.randn(4, 5, device=DEV, requires_grad=True), alpha=torch.full((4, 1), 1.5, device=DEV))
+    # gradients with respect to X and to alpha (entmax.py:70-98) against the reference's own, for a random dY: the forward is the
+    # HIP per-row map, the backward the reference's formulas as device tensor ops on its output
+    from golden_util import load_entmax_row_alpha_grads
+    for m, X, A, dY, dX, dA in load_entmax_row_alpha_grads():
+        Xt, At = torch.from_numpy(X).to(DEV).requires_grad_(True), torch.from_numpy(A).to(DEV).requires_grad_(True)
+        Y = entmax_bisect(Xt, alpha=At, dim=m["dim"], n_iter=m["n_iter"], ensure_sum_one=m["ensure_sum_one"])
+        (Y * torch.from_numpy(dY).to(DEV)).sum().backward()
+        ex = float(np.max(np.abs(Xt.grad.cpu().numpy() - dX))) / max(1.0, float(np.max(np.abs(dX))))
+        ea = float(np.max(np.abs(At.grad.cpu().numpy() - dA))) / max(1.0, float(np.max(np.abs(dA))))
+        print(f"{m['key']}: dX {ex:.2e}, d alpha {ea:.2e} (of the largest element)")
+        assert tuple(At.grad.shape) == A.shape and ex <= 2e-5 and ea <= 2e-4, (m, ex, ea)
 
 
 def test_entmax_edge_rows_on_device():

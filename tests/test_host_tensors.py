@@ -199,3 +199,16 @@ def test_entmax_with_a_tensor_alpha_on_host_tensors_is_the_reference_bit_for_bit
             got = entmax_bisect(torch.from_numpy(X), alpha=torch.from_numpy(A), dim=m["dim"], n_iter=m["n_iter"],
                                 ensure_sum_one=m["ensure_sum_one"]).numpy()
         np.testing.assert_array_equal(got, P, err_msg=str(m))
+
+
+def test_entmax_gradients_with_a_tensor_alpha_on_host_tensors_are_the_reference_bit_for_bit():
+    """utils/entmax.py:70-98: dX and d alpha (per-row, partially broadcast and 0-dim alpha) for a random dY"""
+    import numpy as np
+    import torch
+    from golden_util import load_entmax_row_alpha_grads
+    from utils.entmax import entmax_bisect
+    for m, X, A, dY, dX, dA in load_entmax_row_alpha_grads():
+        Xt, At = torch.from_numpy(X).requires_grad_(True), torch.from_numpy(A).requires_grad_(True)
+        (entmax_bisect(Xt, alpha=At, dim=m["dim"], n_iter=m["n_iter"], ensure_sum_one=m["ensure_sum_one"]) * torch.from_numpy(dY)).sum().backward()
+        np.testing.assert_array_equal(Xt.grad.numpy(), dX, err_msg=str(m))
+        np.testing.assert_array_equal(At.grad.numpy(), dA, err_msg=str(m))
