@@ -168,8 +168,8 @@ def _entmax_raw(X, alpha, dim, n_iter, ensure_sum_one, flags):
 
 class _EntmaxFn(torch.autograd.Function):
     """forward: armnet_entmax_f32; backward: the Jacobian-vector product of utils/entmax.py:70-80 on the saved output
-    (softmax's for alpha == 1).  The gradient with respect to alpha (entmax.py:82-98) is not provided: alpha is a
-    float hyper-parameter on every call path of the reference's models."""
+    (softmax's for alpha == 1).  alpha is a float here — a float hyper-parameter on every call path of the reference's models —;
+    a TENSOR alpha (per row, or one that wants its gradient, entmax.py:82-98) takes _EntmaxRowsFn below."""
 
     @staticmethod
     def forward(ctx, X, alpha, dim, n_iter, ensure_sum_one, flags):

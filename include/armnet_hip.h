@@ -177,7 +177,8 @@ int armnet_entmax_rows_f32(int64_t rows, int d, const float* alpha_rows, int n_i
 /*
  * Backward of the sparse map w.r.t. its input (utils/entmax.py:70-80; softmax's Jacobian for alpha == 1), rows over the
  * last dim: Y = the forward's output [rows, d], dY its gradient, dX [rows, d] (may alias dY).  The gradient w.r.t. alpha
- * (entmax.py:81-98) is not provided: alpha is a float hyper-parameter on every call path of the reference's models.
+ * (entmax.py:81-98) is not part of this entry point: with a float alpha there is none to give; a tensor alpha goes through
+ * armnet_entmax_rows_f32 and the host wrapper's tensor operations (round 6).
  */
 int armnet_entmax_bwd_f32(int64_t rows, int d, float alpha, const float* Y, const float* dY, float* dX, void* stream);
 
