@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("ARMNET_HIP_LIB", os.path.join(_PKG, "lib", "libarmnet_hip.so"))  # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
@@ -37,7 +37,7 @@ EXPORTS = (
     "armnet_gather_map_stats_f32", "armnet_shard_gather_perm_f32",
     "armnet_shard_route_fixed_epoch",
     "armnet_shard_route_fixed_hot", "armnet_shard_route_fixed_perm_hot", "armnet_shard_gather_perm_hot_f32",
-    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32", "armnet_entmax_rows_f32",
+    "armnet_linear_bf16x3_f32", "armnet_mlp_head_ex_f32", "armnet_entmax_rows_f32", "armnet_sibling_kernel_kind",
 )
 
 _lib = None
@@ -161,6 +161,15 @@ def fused_kernel_kind(F, E, O, alpha, n_iter=50, flags=0):
     """1 = the matrix-core kernel serves this shape, 0 = the generic kernel (host-only query)"""
     rc = load().armnet_fused_kernel_kind(int(F), int(E), int(O), ctypes.c_float(alpha), int(n_iter),
                                          ctypes.c_uint32(flags))
+    if rc < 0:
+        check(rc)
+    return rc
+
+
+def sibling_kernel_kind(afn, F, E, O):
+    """1: GC-ARM's (afn = False) / AFN's (afn = True) fused forward runs on the matrix-core kernel for this block shape, 0: on
+    the shape-agnostic one"""
+    rc = load().armnet_sibling_kernel_kind(int(bool(afn)), int(F), int(E), int(O))
     if rc < 0:
         check(rc)
     return rc

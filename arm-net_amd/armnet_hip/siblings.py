@@ -10,7 +10,7 @@ the element-wise maps around the contraction:
 
 Eval-mode inference runs on armnet_gc_fused_fwd_f32 / armnet_afn_fused_fwd_f32 + the HIP prediction head.  Training
 (train.py:108-114 with --model gc_arm / afn):
-  * round 4, nemb <= 64 and nfield <= 48 — the block as ONE autograd.Function around the fused kernels (_GcBlockFn /
+  * round 4, nemb <= 64 and nfield <= 48 (round 6: also nemb 65..128 with nfield <= 32) — the block as ONE autograd.Function around the fused kernels (_GcBlockFn /
     _AfnBlockFn): armnet_gather_map_stats_f32 (lookup * value, exp / log, emb_bn's batch sums), the fused forward with this
     batch's emb_bn affine, HIP BatchNorm passes for the block's BatchNorm, armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32
     on the matrix cores, emb_bn's backward sums and armnet_bn_bwd_scatter_f32.  No [B, K*H, F] tensor is written.

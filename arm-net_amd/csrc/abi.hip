@@ -67,6 +67,11 @@ int armnet_fused_kernel_kind(int F, int E, int O, float alpha, int n_iter, uint3
     return (!(flags & ARMNET_F_FORCE_GENERIC) && fused_mfma_supports(F, E, O)) ? 1 : 0;
 }
 
+int armnet_sibling_kernel_kind(int afn, int F, int E, int O) {
+    if (F <= 0 || E <= 0 || O <= 0) return ARMNET_ERR_BAD_ARG;
+    return fused_mfma_supports_model(F, E, O, afn ? MODEL_AFN : MODEL_GC_ARM) ? 1 : 0;
+}
+
 static int fused_common(FusedArgs& a, float alpha, int n_iter, void* stream) {
     if (a.B < 0 || a.F <= 0 || a.E <= 0 || a.O <= 0 || n_iter < 0) return ARMNET_ERR_BAD_ARG;
     if (a.B == 0) return ARMNET_OK;                       // empty batch: pointers may be null

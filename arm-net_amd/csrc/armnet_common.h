@@ -356,6 +356,7 @@ int launch_fused_generic(const FusedArgs& a, hipStream_t s);
 // returns ARMNET_ERR_UNSUPPORTED when the shape has no MFMA specialisation
 int launch_fused_mfma(const FusedArgs& a, hipStream_t s);
 bool fused_mfma_supports(int F, int E, int O);
+bool fused_mfma_supports_model(int F, int E, int O, int model);      // MODEL_ARM / MODEL_GC_ARM / MODEL_AFN
 int launch_fused_bwd(const BwdArgs& a, hipStream_t s);
 // matrix-core backward; ARMNET_ERR_UNSUPPORTED when the shape has no instantiation
 int launch_fused_bwd_mfma(const BwdArgs& a, hipStream_t s);

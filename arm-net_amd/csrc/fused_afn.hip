@@ -18,7 +18,8 @@ static int launch_afn_e(const FusedArgs& a, int nq, hipStream_t st) {
 }
 
 int launch_afn(const FusedArgs& a, int ep, int nq, hipStream_t st) {
-    return ep == 16 ? launch_afn_e<16>(a, nq, st) : ep == 32 ? launch_afn_e<32>(a, nq, st) : launch_afn_e<64>(a, nq, st);
+    return ep == 16 ? launch_afn_e<16>(a, nq, st) : ep == 32 ? launch_afn_e<32>(a, nq, st)
+         : ep == 64 ? launch_afn_e<64>(a, nq, st) : launch_afn_e<128>(a, nq, st);     // 128: nemb 65..128 (round 6)
 }
 
 }  // namespace armnet

@@ -4,8 +4,8 @@
 
 namespace armnet {
 
-// nemb 4..64, nfield <= 48, any afn_hid (slices); wider shapes keep the composed device ops (siblings.py)
-static bool afn_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 64 || O < 1 || F < 1 || F > 48); }
+// nemb 4..128 (above 64: nfield <= 32), nfield <= 48, any afn_hid (slices); wider shapes keep the composed device ops (siblings.py)
+static bool afn_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 128 || O < 1 || F < 1 || F > (E > 64 ? 32 : 48)); }
 
 template <int E>
 static int launch_afn_nq(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st) {
@@ -14,10 +14,13 @@ static int launch_afn_nq(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream
         case 4: return launch_bwd_afn_t<E, 4>(a, gx, st);
         case 6: return launch_bwd_afn_t<E, 6>(a, gx, st);
         case 8: return launch_bwd_afn_t<E, 8>(a, gx, st);
-        case 10: return launch_bwd_afn_t<E, 10>(a, gx, st);
-        case 12: return launch_bwd_afn_t<E, 12>(a, gx, st);
-        default: return ARMNET_ERR_UNSUPPORTED;
+        default: break;
     }
+    if constexpr (E <= 64) {                           // 33+ fields x 128 floats: the wave tiles do not fit the LDS
+        if (nq == 10) return launch_bwd_afn_t<E, 10>(a, gx, st);
+        if (nq == 12) return launch_bwd_afn_t<E, 12>(a, gx, st);
+    }
+    return ARMNET_ERR_UNSUPPORTED;
 }
 
 static int launch_afn_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st) {
@@ -25,7 +28,7 @@ static int launch_afn_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st)
     if (!afn_bwd_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
-    const int slice = 16 * bwd_passes_model(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64, MODEL_AFN);
+    const int slice = 16 * bwd_passes_model(a.E <= 16 ? 16 : a.E <= 32 ? 32 : a.E <= 64 ? 64 : 128, MODEL_AFN);
     for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
         BwdExtra gx = gx0;
@@ -39,7 +42,7 @@ static int launch_afn_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st)
         if (a.bn_a) { s.bn_a = a.bn_a + o0; s.bn_b = a.bn_b + o0; s.bn_c = a.bn_c + o0; }
         s.d_values = a.d_values + (size_t)o0 * a.F;
         const int rc = a.E <= 16 ? launch_afn_nq<16>(s, gx, nq, st) : a.E <= 32 ? launch_afn_nq<32>(s, gx, nq, st)
-                                                                                : launch_afn_nq<64>(s, gx, nq, st);
+                     : a.E <= 64 ? launch_afn_nq<64>(s, gx, nq, st) : launch_afn_nq<128>(s, gx, nq, st);
         if (rc != ARMNET_OK) return rc;
     }
     return ARMNET_OK;

@@ -870,12 +870,13 @@ int launch_bwd_mfma_e16(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e32(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e64(const BwdArgs& a, int nq, hipStream_t st);
 int launch_bwd_mfma_e128(const BwdArgs& a, int nq, hipStream_t st);    // nq 2..8 (wider samples do not fit the LDS)
-// GC-ARM (fused_bwd_gc_*.hip): nemb <= 64
+// GC-ARM (fused_bwd_gc_*.hip)
 int launch_bwd_gc_e16(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 int launch_bwd_gc_e32(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
 int launch_bwd_gc_e64(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);
+int launch_bwd_gc_e128(const BwdArgs& a, const BwdExtra& gx, int nq, hipStream_t st);   // nq 2..8, like launch_bwd_mfma_e128
 
-// AFN (fused_bwd_afn.hip): nemb <= 64; no sparse map, so one solver-mode instantiation per shape
+// AFN (fused_bwd_afn.hip): no sparse map, so one solver-mode instantiation per shape
 template <int E, int NQ>
 static int launch_bwd_afn_t(const BwdArgs& a, const BwdExtra& gx, hipStream_t st) {
     if (a.id_type == ARMNET_ID_I64) return launch_bwd_one<E, NQ, SOLVE_SOFTMAX, 0, MODEL_AFN>(a, gx, st);

@@ -4,15 +4,16 @@
 
 namespace armnet {
 
-// nemb 4..64, nfield <= 48, any neuron count (slices); wider shapes keep the composed device ops (siblings.py)
-static bool gc_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 64 || O < 1 || F < 1 || F > 48); }
+// nemb 4..128 (above 64: nfield <= 32, like ARM-Net's own backward), nfield <= 48, any neuron count (slices); wider shapes keep
+// the composed device ops (siblings.py)
+static bool gc_bwd_supports(int F, int E, int O) { return !(E < 4 || E > 128 || O < 1 || F < 1 || F > (E > 64 ? 32 : 48)); }
 
 static int launch_gc_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
     if (!gc_bwd_supports(a.F, a.E, a.O)) return ARMNET_ERR_UNSUPPORTED;
     if (a.B * a.F >= ((int64_t)1 << 31)) return ARMNET_ERR_UNSUPPORTED;
     const int nq = (((a.F + 3) / 4) + 1) & ~1;
-    const int slice = 16 * bwd_passes_model(a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64, MODEL_GC_ARM);
+    const int slice = 16 * bwd_passes_model(a.E <= 16 ? 16 : a.E <= 32 ? 32 : a.E <= 64 ? 64 : 128, MODEL_GC_ARM);
     for (int o0 = 0; o0 < a.O; o0 += slice) {
         BwdArgs s = a;
         BwdExtra gx = gx0;
@@ -27,7 +28,7 @@ static int launch_gc_bwd(const BwdArgs& a, const BwdExtra& gx0, hipStream_t st) 
         s.d_values = a.d_values + (size_t)o0 * a.F;
         s.d_qfold = a.d_qfold + (size_t)o0 * a.E;
         const int rc = a.E <= 16 ? launch_bwd_gc_e16(s, gx, nq, st) : a.E <= 32 ? launch_bwd_gc_e32(s, gx, nq, st)
-                                                                                  : launch_bwd_gc_e64(s, gx, nq, st);
+                     : a.E <= 64 ? launch_bwd_gc_e64(s, gx, nq, st) : launch_bwd_gc_e128(s, gx, nq, st);
         if (rc != ARMNET_OK) return rc;
     }
     return ARMNET_OK;

@@ -46,12 +46,12 @@ static int mfma_slice(int F, int E, int O, int model) {
 
 static bool mfma_supports_model(int F, int E, int O, int model) {
     if (E < 4 || E > 128 || O < 1 || O > 1024 || F < 1 || F > 48) return false;
-    if (E > 64 && model != MODEL_ARM) return false;                      // the sibling modes are instantiated up to nemb 64
     const int slice = mfma_slice(F, E, O, model);
     return mfma_cu_waves(F, E, O < slice ? O : slice, model) > 0;
 }
 
 bool fused_mfma_supports(int F, int E, int O) { return mfma_supports_model(F, E, O, MODEL_ARM); }
+bool fused_mfma_supports_model(int F, int E, int O, int model) { return mfma_supports_model(F, E, O, model); }
 
 int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
     if (a.B == 0) return ARMNET_OK;
@@ -72,9 +72,10 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
         s.out = a.out + (size_t)o0 * a.E;
         if (a.model == MODEL_AFN) s.lin_bias = a.lin_bias + o0;
         int rc;
-        if (a.model == MODEL_AFN) rc = launch_afn(s, a.E <= 16 ? 16 : a.E <= 32 ? 32 : 64, nq, st);
+        if (a.model == MODEL_AFN) rc = launch_afn(s, padded_nemb(a.E), nq, st);
         else if (a.model == MODEL_GC_ARM)
-            rc = a.E <= 16 ? launch_gc_e16(s, nq, st) : a.E <= 32 ? launch_gc_e32(s, nq, st) : launch_gc_e64(s, nq, st);
+            rc = a.E <= 16 ? launch_gc_e16(s, nq, st) : a.E <= 32 ? launch_gc_e32(s, nq, st)
+               : a.E <= 64 ? launch_gc_e64(s, nq, st) : launch_gc_e128(s, nq, st);
         else if (a.E <= 16) rc = launch_mfma_e16(s, nq, st);
         else if (a.E <= 32) rc = launch_mfma_e32(s, nq, st);
         else if (a.E <= 64) rc = launch_mfma_e64(s, nq, st);

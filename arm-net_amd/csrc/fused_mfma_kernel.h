@@ -1216,6 +1216,7 @@ int launch_mfma_e128b(const FusedArgs& a, int nq, hipStream_t st);    // nq 8..1
 int launch_gc_e16(const FusedArgs& a, int nq, hipStream_t st);
 int launch_gc_e32(const FusedArgs& a, int nq, hipStream_t st);
 int launch_gc_e64(const FusedArgs& a, int nq, hipStream_t st);
+int launch_gc_e128(const FusedArgs& a, int nq, hipStream_t st);      // nemb 65..128 (round 6)
 int launch_afn(const FusedArgs& a, int ep, int nq, hipStream_t st);
 
 }  // namespace armnet

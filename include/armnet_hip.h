@@ -36,7 +36,7 @@ extern "C" {
  *               armnet_gather_map_stats_f32, armnet_bn_bwd_scatter_f32
  *   5  round 5: hot-row replication of the row-sharded lookup (armnet_shard_route_fixed_hot, _perm_hot,
  *               armnet_shard_gather_perm_hot_f32); armnet_linear_bf16x3_f32 (the training head's GEMMs) */
-#define ARMNET_ABI_VERSION 6
+#define ARMNET_ABI_VERSION 7
 
 typedef enum armnet_status {
     ARMNET_OK = 0,
@@ -368,6 +368,11 @@ int armnet_shard_gather_perm_hot_f32(int64_t n_rows, int E, const int32_t* idx, 
 int armnet_shard_direct_perm(int64_t n, const void* ids, int id_type, int R, int64_t nfeat, int32_t* perm,
                              int32_t* id_status, void* stream);
 
+/* Which kernel the sibling models' fused forward gets for a block shape (round 6): 1 = the matrix-core kernel (nemb 4..128 —
+ * 65..128 since round 6 —, nfield <= 48, <= 1024 neurons), 0 = the shape-agnostic thread-per-row kernel.  afn: 0 = GC-ARM
+ * (models/gc_arm.py), 1 = AFN (models/afn.py).  (armnet_fused_kernel_kind answers the same for ARM-Net itself.) */
+int armnet_sibling_kernel_kind(int afn, int F, int E, int O);
+
 /*
  * Sibling models on the same kernels, eval mode.
  *
@@ -401,7 +406,7 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
 
 /*
  * GC-ARM's block backward on the matrix cores (round 4) — the training step of `train.py:108-114 --model gc_arm`
- * (models/gc_arm.py:82-95 under autograd), one kernel per slice of 64 (nemb <= 16) / 32 (nemb <= 32) / 16 (nemb <= 64) neurons:
+ * (models/gc_arm.py:82-95 under autograd), one kernel per slice of 64 (nemb <= 16) / 32 (nemb <= 32) / 16 (nemb <= 128) neurons:
  *   inputs as armnet_gc_fused_fwd_f32; emb_scale / emb_shift = the affine emb_bn applies to exp(x) in THIS step
  *   (training mode: from the batch statistics, armnet_bn_finalize_f32);  z = the pre-arm_bn block output of the forward
  *   run with an identity bn_scale / bn_shift;  dy = the gradient of z, or — with coefA/B/C (armnet_bn_bwd_coef_f32, all
@@ -415,7 +420,8 @@ int armnet_abs_clamp_min_f32(float* p, int64_t n, float lo, void* stream);
  * The global context (gc_arm.py:37-41) adds the same number to every gate of a row; the sparse map is invariant to
  * that, its Jacobian's rows sum to zero, and the context's gradient is analytically zero (the reference's autograd
  * produces rounding noise there) — it is not formed.
- * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..64, nfield <= 48); otherwise
+ * armnet_gc_fused_bwd_supported: 1 when the shape has a kernel (nemb 4..64 with nfield <= 48; since round 6 nemb 65..128 with
+ * nfield <= 32, the range of armnet_fused_bwd_f32's own matrix-core kernel — the same for armnet_afn_fused_bwd_supported); otherwise
  * ARMNET_ERR_UNSUPPORTED and the caller keeps its composed device ops.
  */
 /*

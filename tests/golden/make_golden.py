@@ -321,6 +321,8 @@ def main():
     sibling_grad_cases()
     round4_sibling_grad_cases()
     round4_sibling_wide_cases()
+    round6_sibling_nemb128_cases()
+    round6_sibling_nemb128_grad_cases()
 
 
 def run_sh_cases():
@@ -550,6 +552,26 @@ def round4_sibling_wide_cases():
     _sibling_case("s2_afn_avazu_h24_e64_stress", "afn", base(22, 300, 64, 1.0, 24), 12, 165, "stress")
 
 
+def round6_sibling_nemb128_cases():
+    """round 6: the siblings' fused forward in the E = 128 kernel family (nemb 65..128; the reference's best-AUC ARM-Net command
+    uses nemb 100, README.md:32-42 — the same width for its GC-ARM / AFN baselines), Frappe- and Criteo-wide field counts"""
+    _sibling_case("s1_gcarm_frappe_k2_e100_a1.7_stress", "gc", base(10, 300, 100, 1.7, 10, nhead=2, mlp_nhid=16), 12, 181, "stress")
+    _sibling_case("s1_gcarm_criteo_k1_e72_a2.0_stress", "gc", base(39, 300, 72, 2.0, 8, nhead=1, mlp_nhid=16), 8, 182, "stress")
+    _sibling_case("s2_afn_frappe_h10_e100_stress", "afn", base(10, 300, 100, 1.0, 10, mlp_nhid=16), 12, 183, "stress")
+    _sibling_case("s2_afn_criteo_h16_e96_fresh", "afn", base(39, 300, 96, 1.0, 16, mlp_nhid=16), 8, 184, "fresh")
+
+
+def round6_sibling_nemb128_grad_cases():
+    """round 6: the siblings' fused training step in the E = 128 kernel family (nemb 65..128, nfield <= 32): the reference's own
+    gradients at the README's nemb = 100 on Frappe's 10 fields, and at a width that is not a multiple of 16"""
+    _sibling_grad_case("s3_grad_gcarm_k2_e100_a1.7_train_b128", "gc", base(10, 128, 100, 1.7, 10, nhead=2, mlp_nhid=16), 128, 191, True)
+    _sibling_grad_case("s3_grad_gcarm_k1_e72_a2.0_ens_train_b128", "gc",
+                       base(22, 128, 72, 2.0, 20, nhead=1, ensemble=True, mlp_nhid=16, deep_nhid=16), 128, 192, True)
+    _sibling_grad_case("s3_grad_afn_h10_e100_train_b128", "afn", base(10, 128, 100, 2.0, 10, mlp_nhid=16), 128, 193, True)
+    _sibling_grad_case("s3_grad_afn_h20_e77_ens_train_b128", "afn",
+                       base(22, 128, 77, 2.0, 20, ensemble=True, mlp_nhid=16, deep_nhid=16), 128, 194, True)
+
+
 def round4_sibling_grad_cases():
     """round 4: the siblings' fused training step (armnet_gc_fused_bwd_f32 / armnet_afn_fused_bwd_f32) at the kernel families the
     round-3 fixtures do not reach: nemb padded to 32 and to 64 (one 16-neuron pass per launch, several slices), alpha = 1.5"""
@@ -670,6 +692,10 @@ def entmax_row_alpha_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--entmax-row-alpha-only":     # round 6: add without rewriting the others
         entmax_row_alpha_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round6-sibling-nemb128-only":
+        round6_sibling_nemb128_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round6-sibling-nemb128-grad-only":
+        round6_sibling_nemb128_grad_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--round4-only":         # add the round-4 cases without rewriting the others
         round4_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--siblings-only":

@@ -65,6 +65,8 @@ def test_abi_argument_validation_without_device():
     assert lib.armnet_entmax_bwd_f32(i64(0), 8, f32(1.5), None, None, None, None) == native.OK
     # GC-ARM's block backward (round 4)
     assert lib.armnet_gc_fused_bwd_supported(39, 16, 64) == 1 and lib.armnet_gc_fused_bwd_supported(39, 65, 64) == 0
+    assert lib.armnet_gc_fused_bwd_supported(32, 65, 64) == 1 and lib.armnet_gc_fused_bwd_supported(10, 128, 700) == 1   # round 6
+    assert lib.armnet_gc_fused_bwd_supported(33, 100, 8) == 0 and lib.armnet_gc_fused_bwd_supported(10, 129, 8) == 0
     assert lib.armnet_gc_fused_bwd_supported(49, 16, 64) == 0 and lib.armnet_gc_fused_bwd_supported(10, 3, 8) == 0
     assert lib.armnet_gc_fused_bwd_f32(i64(8), 39, 16, 32, f32(2.0), 50, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
                                        *([None] * 14)) == native.ERR_BAD_ARG
@@ -76,6 +78,11 @@ def test_abi_argument_validation_without_device():
     assert lib.armnet_gather_map_stats_f32(i64(8), 4, 16, None, 0, None, None, i64(100), 0, None, None, None, None) == native.ERR_BAD_ARG
     assert lib.armnet_gather_map_stats_f32(i64(0), 4, 16, None, 0, None, None, i64(100), 1, None, None, None, None) == native.OK
     assert lib.armnet_afn_fused_bwd_supported(39, 64, 64) == 1 and lib.armnet_afn_fused_bwd_supported(39, 65, 64) == 0
+    assert lib.armnet_afn_fused_bwd_supported(32, 100, 64) == 1 and lib.armnet_afn_fused_bwd_supported(33, 100, 64) == 0
+    assert lib.armnet_afn_fused_bwd_supported(10, 129, 8) == 0
+    k = native.sibling_kernel_kind                                  # siblings' fused forward: nemb <= 128 on the matrix cores (round 6)
+    assert k(False, 39, 16, 32) == 1 and k(True, 39, 16, 32) == 1 and k(False, 39, 100, 24) == 1 and k(True, 48, 128, 40) == 1
+    assert k(False, 60, 16, 8) == 0 and k(True, 10, 200, 8) == 0
     assert lib.armnet_afn_fused_bwd_f32(i64(8), 39, 16, 32, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),
                                         *([None] * 12)) == native.ERR_BAD_ARG
     assert lib.armnet_afn_fused_bwd_f32(i64(0), 39, 16, 32, ctypes.c_uint32(0), None, 0, *([None] * 2), i64(100),

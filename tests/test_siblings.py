@@ -138,6 +138,8 @@ GC_FUSED_SHAPES = [  # nfield, nemb, nhead, arm_hid, alpha, batch  (one / severa
     (39, 16, 2, 32, 1.7, 512), (10, 10, 1, 20, 2.0, 300), (22, 32, 2, 8, 1.5, 257), (5, 8, 3, 7, 1.0, 130),
     (43, 16, 1, 70, 2.5, 96), (48, 12, 4, 40, 2.0, 64), (3, 4, 1, 1, 1.3, 33), (30, 27, 2, 24, 1.5, 200),
     (22, 64, 2, 20, 2.0, 100), (39, 48, 1, 33, 1.7, 70),          # nemb 33..64: one 16-neuron pass per launch
+    (10, 100, 2, 16, 1.7, 200), (22, 128, 1, 20, 2.0, 100), (30, 72, 2, 8, 1.0, 64), (32, 65, 1, 33, 1.5, 70),   # nemb 65..128 (round 6)
+    (5, 96, 3, 7, 2.5, 130),
 ]
 
 
@@ -196,7 +198,8 @@ def test_gc_fused_training_step_matches_the_composed_device_ops(F, E, K, H, alph
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("F,E,O,B", [(39, 16, 64, 512), (10, 10, 20, 300), (22, 32, 40, 257), (5, 8, 7, 130), (43, 16, 70, 96),
-                                     (48, 12, 100, 64), (3, 4, 1, 33), (30, 27, 24, 200), (22, 64, 40, 100), (39, 48, 33, 70)])
+                                     (48, 12, 100, 64), (3, 4, 1, 33), (30, 27, 24, 200), (22, 64, 40, 100), (39, 48, 33, 70),
+                                     (10, 100, 10, 200), (22, 128, 40, 100), (32, 65, 33, 70), (13, 96, 16, 130), (5, 77, 7, 64)])
 def test_afn_fused_training_step_matches_the_composed_device_ops(F, E, O, B):
     """AFN's training step through armnet_afn_fused_bwd_f32 against the composed device ops (see the GC-ARM test above)"""
     from armnet_hip import native
@@ -263,9 +266,18 @@ def test_sibling_backward_kernels_against_a_float64_restatement_over_shapes():
                 assert scan.case(kind, F, E, O, alpha, 37, g) == 0.0, (kind, F, E, O, alpha)
                 n += 1
     assert n > 300
+    for F in (1, 4, 5, 10, 17, 22, 31, 32):                                      # the E = 128 kernel family (round 6): nfield <= 32
+        for E in (65, 72, 77, 96, 100, 128):
+            if (F + E) % 2:
+                continue
+            for O, kind, alpha in ((1, "gc", 2.0), (20, "gc", 1.7), (40, "gc", 1.0), (33, "gc", 1.5), (20, "afn", 1.0), (40, "afn", 1.0)):
+                assert scan.case(kind, F, E, O, alpha, 37, g) == 0.0, (kind, F, E, O, alpha)
+                n += 1
+    assert n > 400
     for B in (1, 2, 5, 64, 65, 1025, 4099):                                      # batch sizes around the wave / block granularity
         for F, E, O, kind, alpha in ((39, 16, 64, "gc", 1.7), (22, 32, 33, "gc", 1.5), (5, 64, 17, "gc", 1.0),
-                                     (39, 16, 64, "afn", 1.0), (7, 64, 16, "afn", 1.0)):
+                                     (39, 16, 64, "afn", 1.0), (7, 64, 16, "afn", 1.0), (10, 100, 20, "gc", 1.7),
+                                     (22, 128, 17, "afn", 1.0)):
             assert scan.case(kind, F, E, O, alpha, B, g) == 0.0, (kind, F, E, O, alpha, B)
 
 
@@ -562,7 +574,11 @@ def _grid_model(variant, F, E, K, nhid, alpha, seed):
 GRID = [("gc", 39, 16, 2, 16, 2.0), ("gc", 39, 16, 1, 24, 1.5), ("gc", 22, 10, 4, 8, 1.7), ("gc", 10, 5, 1, 7, 1.0),
         ("gc", 13, 32, 2, 20, 2.5), ("gc", 43, 64, 1, 33, 1.3), ("gc", 3, 4, 1, 1, 2.0), ("gc", 30, 24, 3, 100, 1.5),
         ("afn", 39, 16, 1, 32, 0.0), ("afn", 22, 10, 1, 600, 0.0), ("afn", 7, 5, 1, 9, 0.0), ("afn", 13, 32, 1, 40, 0.0),
-        ("afn", 43, 64, 1, 17, 0.0), ("afn", 48, 7, 1, 3, 0.0)]
+        ("afn", 43, 64, 1, 17, 0.0), ("afn", 48, 7, 1, 3, 0.0),
+        # the 128-wide family (nemb 65...128): two- to twelve-quad field counts, odd widths, neuron slices
+        ("gc", 10, 100, 2, 16, 1.7), ("gc", 39, 72, 1, 24, 2.0), ("gc", 22, 128, 4, 8, 1.0), ("gc", 43, 65, 1, 33, 2.5),
+        ("gc", 5, 96, 3, 50, 1.3), ("afn", 10, 100, 1, 10, 0.0), ("afn", 39, 96, 1, 16, 0.0), ("afn", 48, 128, 1, 40, 0.0),
+        ("afn", 13, 65, 1, 300, 0.0)]
 
 
 @pytest.mark.gpu
@@ -573,7 +589,7 @@ def test_matrix_core_and_generic_block_match_the_oracle(variant, F, E, K, nhid, 
     from armnet_hip import native
     ctor, m = _grid_model(variant, F, E, K, nhid, alpha, seed=F * 100 + E)
     O = K * nhid if variant == "gc" else nhid
-    assert native.fused_kernel_kind(F, E, O, max(alpha, 1.0)) == 1
+    assert native.sibling_kernel_kind(variant == "afn", F, E, O) == 1
     sd = {k: v.numpy() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(5)
     B = 515
