@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--nfeat", type=int, default=1_000_000)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--flags", type=lambda s: int(s, 0), nargs="*", default=[0])
+    ap.add_argument("--cus", type=int, default=0, help="launch on a stream restricted to the first n bits of the CU mask "
+                                                         "(bit i -> XCD i %% 8): is the kernel bound by its CUs or by the fabric?")
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(1)
@@ -38,6 +40,15 @@ def main():
     vals = torch.rand(a.B, a.F, generator=g).to(dev)
     out = torch.empty(a.B, a.O, a.E, device=dev)
     bytes_alg = a.B * (a.F * (12 + 4 * a.E) + 4 * a.O * a.E)
+    if a.cus:
+        import ctypes
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        words = (ctypes.c_uint32 * 8)()
+        for b in range(a.cus):
+            words[b // 32] |= 1 << (b % 32)
+        sp = ctypes.c_void_p()
+        assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, words) == 0
+        torch.cuda.set_stream(torch.cuda.ExternalStream(sp.value, device=dev))
     for fl in a.flags:
         def run():
             native.fused_fwd(a.B, a.F, a.E, a.O, a.alpha, 50, fl, ids, vals, table, qf, values, sc, sh, out)
@@ -54,7 +65,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.steps
-        print(f"flags={fl:#06x} alpha={a.alpha} {a.regime:6s} B={a.B} F={a.F} E={a.E} O={a.O}: {ms * 1e3:8.1f} us  "
+        print((f"CUs {a.cus:3d} " if a.cus else "") + f"flags={fl:#06x} alpha={a.alpha} {a.regime:6s} B={a.B} F={a.F} E={a.E} O={a.O}: {ms * 1e3:8.1f} us  "
               f"{a.B / ms / 1e3:8.1f} Msamp/s  {bytes_alg / ms / 1e6:7.0f} GB/s alg", flush=True)
 
 

@@ -68,17 +68,32 @@ int main(int argc, char** argv) {
     }
     const double bytes_rd = (double)B * F * (8 + 4 + 64), bytes_wr = (double)B * 2048;
     printf("rotating over %d batches\n", ROT);
+    hipStream_t stream = nullptr;      // `gather_stream <rot> cus <n>`: the launches on a stream restricted to the first n CU-mask bits
     auto run = [&](auto kern, int blocks, int st, const char* name) {
-        for (int i = 0; i < 4; ++i) kern<<<blocks, 256>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
+        for (int i = 0; i < 4; ++i) kern<<<blocks, 256, 0, stream>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) kern<<<blocks, 256>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
-        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventRecord(e0, stream);
+        for (int i = 0; i < 20; ++i) kern<<<blocks, 256, 0, stream>>>(ids[i % ROT], vals[i % ROT], table, out[i % ROT], B, F, st);
+        hipEventRecord(e1, stream); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
         printf("%-34s blocks=%5d store=%d : %7.1f us  %6.0f GB/s\n", name, blocks, st, ms * 1e3,
                (bytes_rd + (st ? bytes_wr : 0)) / ms / 1e6);
     };
+    if (argc > 3 && argv[2][0] == 'c') {   // round 6: is the floor a per-CU rate or the fabric's?  (mask bit i -> XCD i % 8)
+        for (int n : {32, 64, 128, 192, 256}) {
+            uint32_t mask[8] = {0};
+            for (int b = 0; b < n; ++b) mask[b / 32] |= 1u << (b % 32);
+            if (hipExtStreamCreateWithCUMask(&stream, 8, mask) != hipSuccess) { printf("no CU mask\n"); return 1; }
+            printf("CUs %3d: ", n);
+            run(k<1>, 1024, 1, "depth1 store");
+            printf("CUs %3d: ", n);
+            run(k<1>, 1024, 0, "depth1 no store");
+            printf("CUs %3d: ", n);
+            run(k<3>, 2048, 1, "depth3 store");
+        }
+        return 0;
+    }
     if (argc > 2) {                    // `gather_stream <rot> quick`: the two configurations bench.py quotes live
         run(k<1>, 512, 1, "depth1 (1 group of loads in flight)");
         run(k<1>, 1024, 1, "depth1 (1 group of loads in flight)");
