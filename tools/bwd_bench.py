@@ -20,8 +20,18 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--flags", type=lambda s: int(s, 0), nargs="*", default=[0])
+    ap.add_argument("--cus", type=int, default=0, help="launch on a stream restricted to the first n bits of the CU mask")
     a = ap.parse_args()
     dev = "cuda:0"
+    if a.cus:
+        import ctypes
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        words = (ctypes.c_uint32 * 8)()
+        for b in range(a.cus):
+            words[b // 32] |= 1 << (b % 32)
+        sp = ctypes.c_void_p()
+        assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, words) == 0
+        torch.cuda.set_stream(torch.cuda.ExternalStream(sp.value, device=dev))
     g = torch.Generator().manual_seed(1)
     table = ((torch.rand(a.nfeat, a.E, generator=g) * 2 - 1) * 0.5).to(dev)
     qf = (torch.randn(a.O, a.E, generator=g) * 0.5).to(dev)
@@ -43,7 +53,7 @@ def main():
             run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.steps
-        print(f"bwd {name:12s} alpha={a.alpha} B={a.B} F={a.F} E={a.E} O={a.O}: {us:9.1f} us  {a.B / us:8.1f} Msamp/s")
+        print((f"CUs {a.cus:3d} " if a.cus else "") + f"bwd {name:12s} alpha={a.alpha} B={a.B} F={a.F} E={a.E} O={a.O}: {us:9.1f} us  {a.B / us:8.1f} Msamp/s")
 
 
 if __name__ == "__main__":
