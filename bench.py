@@ -96,6 +96,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or bool(os.environ.get("ARMNET_BENCH_FORCE_DIST"))   # FORCE: exercise RCCL with 1 rank
+    if world == 1 and use_dist:                     # a plain `python bench.py` has no rendezvous in its environment
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+            os.environ.setdefault(k, v)
     # developer knobs for a 1-GPU box: ARMNET_BENCH_BACKEND=gloo ARMNET_BENCH_DEVICE=0 run the N > 1 flow with
     # several ranks sharing one device (the exchanges of the row-sharded variant are then staged through the host)
     backend = os.environ.get("ARMNET_BENCH_BACKEND", "nccl")
