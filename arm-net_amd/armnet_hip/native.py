@@ -19,7 +19,7 @@ ABI_VERSION = 7
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ID_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 ID_I64, ID_I32 = 0, 1
 ONE_HEAD, MULTI_HEAD, GC_ARM = 0, 1, 2
-F_WRITE_CLAMPED_VALS, F_FAITHFUL_BISECT, F_FORCE_GENERIC, F_NO_LIN_FINISH = 0x1, 0x2, 0x4, 0x8
+F_WRITE_CLAMPED_VALS, F_FAITHFUL_BISECT, F_FORCE_GENERIC, F_NO_LIN_FINISH, F_FP32_CONTRACTIONS = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = (
     "armnet_abi_version", "armnet_strerror", "armnet_last_hip_error", "armnet_fold_params_f32",

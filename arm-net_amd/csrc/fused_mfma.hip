@@ -76,7 +76,16 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
         else if (a.model == MODEL_GC_ARM)
             rc = a.E <= 16 ? launch_gc_e16(s, nq, st) : a.E <= 32 ? launch_gc_e32(s, nq, st)
                : a.E <= 64 ? launch_gc_e64(s, nq, st) : launch_gc_e128(s, nq, st);
-        else if (a.E <= 16) rc = launch_mfma_e16(s, nq, st);
+        else if (a.E <= 16) {
+            // wide blocks: both contractions as fp16 x 2 splits on the 16-bit matrix pipe (F16, fused_mfma_kernel.h)
+            rc = ARMNET_ERR_UNSUPPORTED;
+            // (measured, kbench, B = 65 536: 29+ fields -5..-20 % from 64 neurons up, 17-28 fields -13 % at 512 neurons and +-2 % at
+            // 128; 16 fields or fewer lose 0..24 % — their fp32 form runs at 6-8 waves per SIMD and has little matrix work)
+            if (nq >= 6 && s.O >= (nq >= 8 ? ARMNET_F16_MIN_O : 4 * ARMNET_F16_MIN_O) && s.cfg.mode != SOLVE_BISECT &&
+                !(s.flags & ARMNET_F_FP32_CONTRACTIONS))
+                rc = launch_mfma_e16_f16(s, nq, st);
+            if (rc == ARMNET_ERR_UNSUPPORTED) rc = launch_mfma_e16(s, nq, st);
+        }
         else if (a.E <= 32) rc = launch_mfma_e32(s, nq, st);
         else if (a.E <= 64) rc = launch_mfma_e64(s, nq, st);
         else rc = nq <= 6 ? launch_mfma_e128a(s, nq, st) : launch_mfma_e128b(s, nq, st);

@@ -191,11 +191,55 @@ constexpr OccCfg occ_config(int E, int NQ, int MODE) {
 // ... and whether such a configuration also keeps the last evaluation's clamped differences (alpha = 2 / 1.5)
 constexpr bool occ_keeps(int E, int NQ, int SPW, int WPS) { return E == 16 && WPS >= 5 && occ_config(E, NQ, 0).spw == SPW; }
 
+// F16 (round 6): both contractions on the 16-bit matrix pipe with fp16 x 2 operand splits (three products, fp32 accumulate).
+// The fp32 MFMA issues at the vector unit's own rate (32 cycles per SIMD for 16x16x4) and its cycles add to the VALU's;
+// v_mfma_f32_16x16x32_f16 takes ~17 for eight times the contraction depth.  Per group the wave scales its tile by a power of
+// two (exact) so that the largest |x| sits near 2^10, splits x = hi + lo (fp16 each: 22 significant bits) ONCE into the A
+// operands of both contractions and keeps them in registers over the passes; q_fold and `values` get block-wide scales in the
+// prologue; the weights p * values are split per pass.  G = hi.qh + lo.qh + hi.ql (the lo.ql term, <= 2^-24 of the product,
+// is dropped), descaled by an exact power of two in the multiply the Newton modes have anyway; the same for MFMA #2 with the
+// descale folded into the exponent's factor.  One-sample groups, nemb <= 16, ARM-Net only.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+struct HiLo4 { f16x4 hi, lo; };
+// 4 fp32 (already scaled) -> hi, lo with hi + lo = x to 2^-22 |x| (round to nearest both times)
+__device__ __forceinline__ HiLo4 split4(f32x4 x) {
+    const f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
+    const f16x2v ha = __builtin_convertvector(a, f16x2v), hb = __builtin_convertvector(b, f16x2v);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const f16x2v la = __builtin_convertvector(ra, f16x2v), lb = __builtin_convertvector(rb, f16x2v);
+    HiLo4 r;
+    r.hi = f16x4{ha[0], ha[1], hb[0], hb[1]};
+    r.lo = f16x4{la[0], la[1], lb[0], lb[1]};
+    return r;
+}
+__device__ __forceinline__ f16x8 cat8(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+// Every MFMA of the F16 path starts from C = 0 and the partial tiles are added on the VALU.  With accumulator chains hipcc (ROCm 7.2)
+// is free to give a dependent MFMA a destination other than its source C, and such a pair issued back to back
+// (v_mfma_f32_16x16x32_f16 v[6:9], ... ; v_mfma_f32_16x16x16_f16 v[50:53], ..., v[6:9]) returned wrong values in the first two
+// registers of the tile on gfx950 — embedding columns 4g, 4g+1 of whole passes (tools/experiments/README.md); in-place chains
+// written as asm are correct but serialise nine dependent MFMAs behind hand-counted s_nops and lose the gain.  Independent MFMAs
+// have no source-C hazard at all and leave the scheduling to the compiler; the price is 16 v_pk_add_f32 per pass.
+// 2^k as a float, k clamped to the normal range
+__device__ __forceinline__ float pow2i(int k) {
+    k = k < -126 ? -126 : k > 127 ? 127 : k;
+    return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
+}
+// the power-of-two scale that brings a non-negative maximum m to [2^9, 2^10): exponent k (inf / NaN: a tiny scale, the
+// non-finite value then poisons what it touches as it would in fp32; zero: 0)
+__device__ __forceinline__ int scale_exp(float m) {
+    const int eb = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);
+    const int k = 136 - eb;
+    return eb == 0 ? 0 : (k > 100 ? 100 : k);
+}
+
 // HOIST (round 6, one-sample groups of blocks with MANY 16-neuron passes): the pass-invariant A operands of both
 // contractions — MFMA #1's tile rows (NTILE x EB f32x4) and MFMA #2's transposed scalars (NQ x EB) — are read from the LDS
 // tile ONCE per group and kept in registers across the passes, instead of 3 + 10 LDS reads behind a fence in every pass.
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM, bool HOIST = false>
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL = MODEL_ARM, bool HOIST = false, bool F16 = false>
 __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel(FusedArgs a) {
+    static_assert(!F16 || (E == 16 && SPW == 1 && MODEL == MODEL_ARM && !HOIST && MODE != SOLVE_BISECT), "F16: one-sample groups, nemb <= 16");
     constexpr int NQT = SPW * NQ;             // quarter-steps per group
     constexpr int NTILE = (NQT + 3) / 4;      // 16-row MFMA tiles per group (last one may be half pad)
     constexpr int ES = E + 4;                 // LDS row stride (floats)
@@ -408,6 +452,21 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
     };
 
     if (grp < ngroups) fetch_raw(grp);        // first dependent load of the pipeline: issue before anything else
+    [[maybe_unused]] int kq = 0, kw = 0;      // F16: exponents of the block's scales of q_fold and `values`
+    if constexpr (F16) {
+        float mq = 0.f, mv = 0.f;
+        for (int i = threadIdx.x; i < O * Er; i += nthreads) mq = __builtin_fmaxf(mq, __builtin_fabsf(a.q_fold[i]));
+        for (int i = threadIdx.x; i < O * F; i += nthreads) mv = __builtin_fmaxf(mv, __builtin_fabsf(a.values[i]));
+        uint32_t* sc = reinterpret_cast<uint32_t*>(lds_all);       // wave 0's tile: nobody stages before the barrier below
+        if (threadIdx.x < 2) sc[threadIdx.x] = 0u;
+        __syncthreads();
+        atomicMax(sc + 0, __builtin_bit_cast(uint32_t, mq));       // non-negative floats order like their bit patterns
+        atomicMax(sc + 1, __builtin_bit_cast(uint32_t, mv));
+        __syncthreads();
+        kq = scale_exp(__builtin_bit_cast(float, sc[0]));
+        kw = scale_exp(__builtin_bit_cast(float, sc[1]));
+        __syncthreads();
+    }
     for (int i = threadIdx.x; MODEL != MODEL_AFN && i < NT * EB * 64; i += nthreads) {
         const int l = i & 63, kb = (i >> 6) % EB, nt = (i >> 6) / EB;
         const int o = 16 * nt + (l & 15);
@@ -416,6 +475,10 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         if (o < O)
             for (int r = 0; r < 4; ++r)
                 if (e0 + r < Er) v[r] = a.q_fold[(size_t)o * Er + e0 + r];
+        if constexpr (F16) {                       // the same 16 bytes: {hi x 4, lo x 4} of 2^kq * q_fold
+            const HiLo4 h = split4(v * pow2i(kq));
+            v = __builtin_bit_cast(f32x4, cat8(h.hi, h.lo));
+        }
         *reinterpret_cast<f32x4*>(p_bq + i * 4) = v;
     }
     for (int i = threadIdx.x; i < NT * NP * 64; i += nthreads) {
@@ -430,6 +493,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
             if (f0 < F) v[0] *= a.emb_scale[f0] * kLn2;
             if (f1 < F) v[1] *= a.emb_scale[f1] * kLn2;
         }
+        if constexpr (F16) v *= pow2i(kw);         // the weights p * values come out scaled
         *reinterpret_cast<f32x2*>(p_vv + i * 2) = v;
     }
     if constexpr (MODEL == MODEL_GC_ARM) {
@@ -483,6 +547,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
 #endif
         bool changed = false;
         float vcl[NI];
+        [[maybe_unused]] float xmax = 0.f;             // F16: largest |x| this lane staged
         if constexpr (CO) {
             const int vco = __builtin_bit_cast(int, val_cur[0]);
 #pragma unroll
@@ -513,6 +578,11 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
             }
             const int row = n * RPI + lane / CH;
             *reinterpret_cast<RowT*>(xt + row * ES + chunk * CF) = r;
+            if constexpr (F16) {
+                if (!pad[n])                               // (a pad row is zeroed below; its lanes re-read a real row)
+                    xmax = __builtin_fmaxf(__builtin_fmaxf(xmax, __builtin_fmaxf(__builtin_fabsf(r[0]), __builtin_fabsf(r[1]))),
+                                           __builtin_fmaxf(__builtin_fabsf(r[2]), __builtin_fabsf(r[3])));
+            }
         }
         if (any_pad) {
 #pragma unroll
@@ -556,6 +626,28 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
         wave_lds_fence();
         PHASE(0);
 
+        // F16: the group's scale, then the A operands of both contractions as {hi x 4, lo x 4}, kept over the passes
+        [[maybe_unused]] f16x8 a1f[F16 ? NTILE : 1];    // MFMA #1: tile row 16t + c, embedding columns 4g .. 4g+3
+        [[maybe_unused]] f16x8 a2f[F16 ? NTILE : 1];    // MFMA #2: column c of the tile rows 16J + 4g .. + 3 (quarter-steps 4J .. 4J+3 of field group g)
+        [[maybe_unused]] float dsc_g = 1.f, dsc_z = 1.f;
+        if constexpr (F16) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) xmax = __builtin_fmaxf(xmax, __shfl_xor(xmax, off, 64));
+            const int kx = __builtin_amdgcn_readfirstlane(scale_exp(xmax));
+            const float sx = pow2i(kx);
+            dsc_g = pow2i(-kx) * pow2i(-kq);
+            dsc_z = pow2i(-kx) * pow2i(-kw);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                const HiLo4 h = split4(*reinterpret_cast<const f32x4*>(xt + (16 * t + c) * ES + 4 * g) * sx);
+                a1f[t] = cat8(h.hi, h.lo);
+                f32x4 col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) col[i] = xt[(16 * t + 4 * g + i) * ES + c];
+                const HiLo4 k = split4(col * sx);
+                a2f[t] = cat8(k.hi, k.lo);
+            }
+        }
         f32x4 avh[HOIST ? EB * NTILE : 1];
         float a2h[HOIST ? NQ * EB * SPW : 1];
         if constexpr (HOIST) {
@@ -598,8 +690,25 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                 }
             } else {
                 // ---- MFMA #1: gates; the NTILE accumulator chains are interleaved (40-cycle dependent latency)
+                if constexpr (F16) {
+                    const f16x8 bq = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(p_bq + (nt * 64 + lane) * 4));
+                    const f16x4 qh = {bq[0], bq[1], bq[2], bq[3]}, ql = {bq[4], bq[5], bq[6], bq[7]};
+                    const f16x8 qhh = cat8(qh, qh);
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 part[NTILE];
 #pragma unroll
-                for (int kb = 0; kb < EB; ++kb) {
+                    for (int t = 0; t < NTILE; ++t)         // (x_hi | x_lo) . (q_hi | q_hi)
+                        c1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1f[t], qhh, zero, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) {       // x_hi . q_lo
+                        const f16x4 xh = {a1f[t][0], a1f[t][1], a1f[t][2], a1f[t][3]};
+                        part[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(xh, ql, zero, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTILE; ++t) c1[t] += part[t];
+                }
+#pragma unroll
+                for (int kb = 0; kb < (F16 ? 0 : EB); ++kb) {
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(p_bq + ((nt * EB + kb) * 64 + lane) * 4);
                     f32x4 av[NTILE];
 #pragma unroll
@@ -635,7 +744,11 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     for (int jp = 0; jp < NP; ++jp) {
                         f32x2 x = XP_GET(s, jp);
                         if constexpr (MODE != SOLVE_MICHELOT && MODE != SOLVE_SOFTMAX) {
-                            x *= f32x2{am1, am1};               // entmax.py:42
+                            const float m = F16 ? am1 * dsc_g : am1;      // (a power of two: the same rounding as descale, then * am1)
+                            x *= f32x2{m, m};                   // entmax.py:42
+                            XP_SET(s, jp, x);
+                        } else if constexpr (F16) {
+                            x *= f32x2{dsc_g, dsc_g};
                             XP_SET(s, jp, x);
                         }
                         sm2 = jp == 0 ? x : sm2 + x;            // a pad field's gate is exactly 0
@@ -945,6 +1058,7 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
                     float r = __builtin_amdgcn_rcpf(S);
                     r = fmaf(fmaf(-S, r, 1.0f), r, r);
                     kexp[s] = MODEL == MODEL_GC_ARM ? r : L2E * r;      // GC-ARM: no outer exp (gc_arm.py:92-94)
+                    if constexpr (F16) kexp[s] *= dsc_z;               // the accumulators of MFMA #2 carry 2^(kx + kw)
                 }
             }
 
@@ -952,8 +1066,37 @@ __global__ void __launch_bounds__(64 * mfma_max_wpb(WPS), WPS) fused_mfma_kernel
             const f32x2 bn = *reinterpret_cast<const f32x2*>(p_bn + (nt * 16 + c) * 2);
             const float xb = MODEL == MODEL_AFN ? p_x[nt * 16 + c] : 0.f;
             f32x4 c2[SPW][EB];
+            if constexpr (F16) {
+                // k-tile J = quarter-steps 4J .. 4J+3: the lane's four accumulator elements of MFMA #1's tile J ARE its four
+                // contraction elements (field 4(4J+i) + g), so the weights go from the C layout straight into the B operand
+                f16x4 wh[NTILE], wl[NTILE];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
+                for (int J = 0; J < NTILE; ++J) {
+                    f32x4 w = c1[J];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * J + i >= NQ) w[i] = 0.f;                 // quarter-steps past the sample (compile-time)
+                    const HiLo4 h = split4(w);
+                    wh[J] = h.hi;
+                    wl[J] = h.lo;
+                }
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 pa[NTILE], pb[NTILE];
+#pragma unroll
+                for (int J = 0; J < NTILE; ++J)             // (x_hi | x_lo) . (w_hi | w_hi)
+                    pa[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2f[J], cat8(wh[J], wh[J]), zero, 0, 0, 0);
+#pragma unroll
+                for (int J = 0; J < NTILE; ++J) {           // x_hi . w_lo
+                    const f16x4 xh = {a2f[J][0], a2f[J][1], a2f[J][2], a2f[J][3]};
+                    pb[J] = __builtin_amdgcn_mfma_f32_16x16x16f16(xh, wl[J], zero, 0, 0, 0);
+                }
+                f32x4 acc = pa[0] + pb[0];
+#pragma unroll
+                for (int J = 1; J < NTILE; ++J) acc += pa[J] + pb[J];
+                c2[0][0] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < (F16 ? 0 : NQ); ++j) {
                 f32x2 es = {0.f, 0.f};
                 if constexpr (MODEL == MODEL_GC_ARM) es = *reinterpret_cast<const f32x2*>(p_x + (4 * j + g) * 2);
 #pragma unroll
@@ -1073,7 +1216,7 @@ static inline int mfma_pick_wpb(size_t wave_bytes, size_t param_bytes, int wps, 
 }
 
 // One configuration (samples per wave-group, waves per SIMD) of a shape: sizes the block, launches the persistent grid.
-template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL, bool HOIST = false>
+template <int E, int NQ, int SPW, int MODE, int SRC, int WPS, int MODEL, bool HOIST = false, bool F16 = false>
 static int launch_cfg(const FusedArgs& a, hipStream_t st) {
     constexpr int NTILE = (SPW * NQ + 3) / 4;
     const int NT = (a.O + 15) / 16;
@@ -1115,7 +1258,7 @@ static int launch_cfg(const FusedArgs& a, hipStream_t st) {
         if (want < 1) want = 1;
     }
 #endif
-    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL, HOIST>;
+    auto kern = fused_mfma_kernel<E, NQ, SPW, MODE, SRC, WPS, MODEL, HOIST, F16>;
     ARMNET_ALLOW_BIG_LDS(kern, lds);
     kern<<<(int)want, 64 * wpb, lds, st>>>(a);
     ARMNET_LAUNCH_CHECK();
@@ -1207,8 +1350,33 @@ static int launch_src(const FusedArgs& a, hipStream_t st) {
     return a.id_type == ARMNET_ID_I64 ? launch_mode<E, NQ, 0>(a, st) : launch_mode<E, NQ, 1>(a, st);
 }
 
+// F16 (round 6): the ARM block at nemb <= 16 with both contractions as fp16 x 2 splits — one-sample groups, four waves per SIMD
+// (116-128 registers, no scratch but 12 bytes in the generic-alpha solver); every sparse map but the literal bisection
+#ifndef ARMNET_F16_MIN_O
+#define ARMNET_F16_MIN_O 64        // neurons of a launch from which the split form wins (measured; 32 neurons: -8 %)
+#endif
+#ifndef ARMNET_F16_WPS
+#define ARMNET_F16_WPS 4
+#endif
+template <int NQ, int SRC>
+static int launch_f16_mode(const FusedArgs& a, hipStream_t st) {
+    switch (a.cfg.mode) {
+        case SOLVE_SOFTMAX: return launch_cfg<16, NQ, 1, SOLVE_SOFTMAX, SRC, ARMNET_F16_WPS, MODEL_ARM, false, true>(a, st);
+        case SOLVE_MICHELOT: return launch_cfg<16, NQ, 1, SOLVE_MICHELOT, SRC, ARMNET_F16_WPS, MODEL_ARM, false, true>(a, st);
+        case SOLVE_NEWTON15: return launch_cfg<16, NQ, 1, SOLVE_NEWTON15, SRC, ARMNET_F16_WPS, MODEL_ARM, false, true>(a, st);
+        case SOLVE_NEWTON: return launch_cfg<16, NQ, 1, SOLVE_NEWTON, SRC, ARMNET_F16_WPS, MODEL_ARM, false, true>(a, st);
+        default: return ARMNET_ERR_UNSUPPORTED;
+    }
+}
+template <int NQ>
+static int launch_f16(const FusedArgs& a, hipStream_t st) {
+    if (a.rows != nullptr) return launch_f16_mode<NQ, 2>(a, st);
+    return a.id_type == ARMNET_ID_I64 ? launch_f16_mode<NQ, 0>(a, st) : launch_f16_mode<NQ, 1>(a, st);
+}
+
 // one translation unit per family keeps the build parallel
 int launch_mfma_e16(const FusedArgs& a, int nq, hipStream_t st);
+int launch_mfma_e16_f16(const FusedArgs& a, int nq, hipStream_t st);   // the F16 form (fused_mfma_e16h.hip); UNSUPPORTED: use the above
 int launch_mfma_e32(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e64(const FusedArgs& a, int nq, hipStream_t st);
 int launch_mfma_e128a(const FusedArgs& a, int nq, hipStream_t st);    // nq 2..6
