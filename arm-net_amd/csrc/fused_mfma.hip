@@ -79,10 +79,11 @@ int launch_fused_mfma(const FusedArgs& a, hipStream_t st) {
         else if (a.E <= 16) {
             // wide blocks: both contractions as fp16 x 2 splits on the 16-bit matrix pipe (F16, fused_mfma_kernel.h)
             rc = ARMNET_ERR_UNSUPPORTED;
-            // (measured, kbench, B = 65 536: 29+ fields -5..-20 % from 64 neurons up, 17-28 fields -13 % at 512 neurons and +-2 % at
-            // 128; 16 fields or fewer lose 0..24 % — their fp32 form runs at 6-8 waves per SIMD and has little matrix work)
-            if (nq >= 6 && s.O >= (nq >= 8 ? ARMNET_F16_MIN_O : 4 * ARMNET_F16_MIN_O) && s.cfg.mode != SOLVE_BISECT &&
-                !(s.flags & ARMNET_F_FP32_CONTRACTIONS))
+            // (measured, kbench, B = 65 536: 33+ fields 0..-5 % at 40-48 neurons, -5..-8 % at 56-64, -11..-20 % from 128 up; 29-32 fields
+            // +4 % at 48, -7 % at 128; 17-28 fields +-2 % at 128, -13 % at 512; 16 fields or fewer lose 0..24 % — their fp32 form runs
+            // at 6-8 waves per SIMD and has little matrix work; 32 neurons or fewer: -8 %, five waves per SIMD beat four)
+            const int f16_min_o = nq >= 10 ? 33 : nq >= 8 ? ARMNET_F16_MIN_O : 4 * ARMNET_F16_MIN_O;
+            if (nq >= 6 && s.O >= f16_min_o && s.cfg.mode != SOLVE_BISECT && !(s.flags & ARMNET_F_FP32_CONTRACTIONS))
                 rc = launch_mfma_e16_f16(s, nq, st);
             if (rc == ARMNET_ERR_UNSUPPORTED) rc = launch_mfma_e16(s, nq, st);
         }

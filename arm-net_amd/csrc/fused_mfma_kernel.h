@@ -1353,7 +1353,7 @@ static int launch_src(const FusedArgs& a, hipStream_t st) {
 // F16 (round 6): the ARM block at nemb <= 16 with both contractions as fp16 x 2 splits — one-sample groups, four waves per SIMD
 // (116-128 registers, no scratch but 12 bytes in the generic-alpha solver); every sparse map but the literal bisection
 #ifndef ARMNET_F16_MIN_O
-#define ARMNET_F16_MIN_O 64        // neurons of a launch from which the split form wins (measured; 32 neurons: -8 %)
+#define ARMNET_F16_MIN_O 64        // neurons of a launch from which the split form wins at 29-32 fields (fused_mfma.hip: 33 for 33+ fields, 256 for 17-28)
 #endif
 #ifndef ARMNET_F16_WPS
 #define ARMNET_F16_WPS 4

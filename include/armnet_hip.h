@@ -70,8 +70,8 @@ typedef enum armnet_variant {
 #define ARMNET_F_NO_LIN_FINISH      0x8u /* 1 < alpha < 2 on the matrix-core kernel: every Newton step is confirmed by an
                                             evaluation (no first-order finish of a tiny last step; rounds 1-4 behaviour) —
                                             a run-time switch for bisecting a regression without a rebuild */
-#define ARMNET_F_FP32_CONTRACTIONS  0x10u /* wide ARM blocks (nemb <= 16; 29+ fields from 64 neurons per launch, 17-28 fields from
-                                            256) run both contractions as fp16 x 2 operand splits on the 16-bit matrix pipe
+#define ARMNET_F_FP32_CONTRACTIONS  0x10u /* wide ARM blocks (nemb <= 16; 33+ fields from 33 neurons per launch, 29-32 fields from
+                                            64, 17-28 from 256) run both contractions as fp16 x 2 operand splits on the 16-bit matrix pipe
                                             (three products, fp32 accumulate, exact power-of-two scales per sample / per
                                             parameter slice: 22 significant bits per operand, results within 6e-7 of the
                                             fp32 form); this switch keeps them on the fp32 MFMAs (A/B and parity tests) */

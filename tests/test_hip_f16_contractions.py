@@ -1,4 +1,4 @@
-"""Wide ARM blocks (nemb <= 16; 29+ fields from 64 neurons per launch, 17-28 fields from 256) run both contractions of the block
+"""Wide ARM blocks (nemb <= 16; 33+ fields from 33 neurons per launch, 29-32 fields from 64, 17-28 from 256) run both contractions of the block
 (models/armnet_1h.py:33-36, models/armnet.py:33-36,86-89) as fp16 x 2 operand splits on the 16-bit matrix pipe (F16 in
 csrc/fused_mfma_kernel.h): three products per tile, fp32 accumulate, exact power-of-two scales per sample (embeddings) and per
 parameter slice (q_fold, values).  Held here to the CPU oracle at the tests' bar, to the fp32-MFMA form of the same kernel
@@ -18,7 +18,7 @@ DEV = "cuda:0"
 # every sparse map it serves (softmax, alpha = 1.5, 2, generic)
 SHAPES = [(39, 16, 128, 2.0), (39, 16, 64, 1.7), (39, 10, 256, 1.5), (39, 16, 70, 1.0), (33, 7, 96, 2.0), (40, 16, 128, 1.3),
           (43, 16, 128, 2.0), (48, 12, 64, 1.7), (30, 16, 128, 2.0), (29, 5, 64, 1.5), (22, 16, 512, 2.0), (17, 10, 256, 1.7),
-          (39, 16, 300, 2.0), (39, 4, 64, 1.9)]
+          (39, 16, 300, 2.0), (39, 4, 64, 1.9), (39, 16, 40, 2.0), (43, 10, 48, 1.7), (36, 16, 33, 1.5)]
 
 
 def _case(F, E, O, seed, B=777, nfeat=5003, table_scale=0.9, q_scale=1.5):
