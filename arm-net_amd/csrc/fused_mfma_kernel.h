@@ -215,12 +215,15 @@ __device__ __forceinline__ HiLo4 split4(f32x4 x) {
     return r;
 }
 __device__ __forceinline__ f16x8 cat8(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
-// Every MFMA of the F16 path starts from C = 0 and the partial tiles are added on the VALU.  With accumulator chains hipcc (ROCm 7.2)
-// is free to give a dependent MFMA a destination other than its source C, and such a pair issued back to back
-// (v_mfma_f32_16x16x32_f16 v[6:9], ... ; v_mfma_f32_16x16x16_f16 v[50:53], ..., v[6:9]) returned wrong values in the first two
-// registers of the tile on gfx950 — embedding columns 4g, 4g+1 of whole passes (tools/experiments/README.md); in-place chains
-// written as asm are correct but serialise nine dependent MFMAs behind hand-counted s_nops and lose the gain.  Independent MFMAs
-// have no source-C hazard at all and leave the scheduling to the compiler; the price is 16 v_pk_add_f32 per pass.
+// Every MFMA of the F16 path starts from C = 0 and the partial tiles are added on the VALU (16 v_pk_add_f32 per pass): there is no
+// matrix-to-matrix dependency in it at all.  On gfx950 a v_mfma_f32_16x16x16_f16 that takes its source C from a
+// v_mfma_f32_16x16x32_f16 issued fewer than 5 wait states earlier reads a partly stale C — wrong values in one or two registers of
+// the tile, in place or not; the opposite order needs more — and hipcc (ROCm 7.2) inserts no wait states for such a pair
+// (tools/ubench/mfma_dep_dst.hip; first seen here as errors in embedding columns 4g, 4g+1 of whole passes).  Chains that stay within one
+// instruction pass that reproducer, but a build with them (2-4 % faster) returned values that differed from run to run in one
+// instantiation (softmax, 29-32 fields); in-place chains written as asm behind hand-counted s_nops are correct and slower than the fp32
+// form (tools/experiments/README.md).  The independent form is bit-equal run to run over every tile family, solver and id source
+// (tools/scratch/r6_f16_determinism.py).
 // 2^k as a float, k clamped to the normal range
 __device__ __forceinline__ float pow2i(int k) {
     k = k < -126 ? -126 : k > 127 ? 127 : k;
