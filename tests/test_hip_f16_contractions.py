@@ -90,6 +90,19 @@ def _block_f64_sparsemax(ids, vals, table, qf, values, sc, sh):
     return torch.exp(z) * sc.to(D)[None, :, None] + sh.to(D)[None, :, None]
 
 
+@pytest.mark.parametrize("F,O", [(22, 512), (30, 96), (32, 128), (36, 40), (39, 128), (43, 64), (48, 96)])
+def test_split_contractions_are_run_to_run_deterministic(F, O):
+    """a missing wait state between matrix instructions shows up as values that depend on how fast a wave issues (round 6: a build with
+    accumulator chains failed exactly this at 29-32 fields with the softmax): every solver instantiation, three launches each"""
+    for alpha in (1.0, 1.5, 1.7, 2.0):
+        table, qf, values, sc, sh, ids, vals = _case(F, 16, O, 5 * F + O + int(alpha * 10), B=20011)
+        B = ids.shape[0]
+        z0, _ = _run(B, F, 16, O, alpha, 0, ids, vals, table, qf, values, sc, sh)
+        for _rep in range(2):
+            z, _ = _run(B, F, 16, O, alpha, 0, ids, vals, table, qf, values, sc, sh)
+            assert torch.equal(z, z0), (F, O, alpha)
+
+
 @pytest.mark.parametrize("table_scale,q_scale", [(1e-12, 1.5), (2.0, 1e-3), (0.9, 1e-20), (1e-30, 1e6), (1.5, 6.0), (1.5, 40.0)])
 def test_scales_follow_the_magnitudes(table_scale, q_scale):
     """the per-sample / per-slice power-of-two scales keep the operands inside fp16's range whatever the parameters' magnitude:
